@@ -1,0 +1,495 @@
+// Device-side path-tracing building blocks for gfx950 (wave64).
+//
+// These functions restate, for a flat SoA scene, what the reference does on the device:
+//   camera rays        src/camera.cuh:240-278
+//   BVH4 traversal     src/bvh.cuh:380-421 with the slab test of src/aabb.cuh:132-156
+//   primitive tests    src/hittable.cuh:272-359 under the object transform of :426-446
+//   hit record fill    src/hittable.cuh:292-299, :338-356, :367-386, :438-444
+//   materials          src/material.cuh:290-381, textures src/texture.cuh:252-324
+//   path loop          src/render.cuh:36-98
+//
+// Design notes
+//   * The reference fills a complete hit record at every accepted candidate.  Only the last
+//     accepted one survives, so traversal here carries just (t, object, barycentrics) and
+//     the record is derived once per ray afterwards from the same expressions.
+//   * The slab test's reciprocal depends only on the ray, so it is hoisted out of the box
+//     loop; the near/far plane of every axis is picked by the per-lane ADDRESS of the load
+//     (min or max field) instead of a swap, which is value-identical to aabb.cuh:144-148.
+//   * Objects whose transform is the identity with zero anchor and translation skip the
+//     two 3x3 products: (o - 0 - 0) + 0 and I*v are exact, so results do not change.
+//   * All float expressions keep the reference's association order and the file is built
+//     with -ffp-contract=off: with the shared counter RNG a path is reproducible bit for
+//     bit on a CPU as long as it does not touch acosf/atan2f/sinf/cosf/powf.
+#ifndef CRT_PT_DEVICE_H
+#define CRT_PT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vecmath.h"
+
+namespace crt {
+
+constexpr float kPi = 3.1415926535897932385f;
+constexpr int kNodeFields = 7;        // minx miny minz maxx maxy maxz code   (float4 / int4 each)
+constexpr int kNodeStrideGlobal = 8;  // float4 per node in HBM (one 128-byte line)
+constexpr int kPrimQuads = 3;         // float4 per primitive record
+constexpr int kShadeQuads = 6;        // float4 per shading record
+constexpr int kXformFloats = 24;      // rinv[9] anchor[3] trans[3] rot[9]
+
+struct DevImage {
+    const uint8_t* pixels;
+    int32_t width, height, channels, pad;
+};
+
+struct DevCamera {
+    int32_t type;
+    float defocus_angle;
+    V3 center, llc, du, dv, w, defocus_u, defocus_v;
+};
+
+// Everything a kernel needs, passed by value (lands in SGPRs / scalar loads).
+struct DevScene {
+    const float4* nodes;      // [node_count][8]     node-major
+    const float4* prims;      // [object_count][3]
+    const float4* shade;      // [object_count][6]
+    const float* xforms;      // [xform_count][24]
+    const float4* mats;       // [material_count][2]
+    const float4* texs;       // [texture_count][2]
+    const DevImage* images;
+    int32_t node_count, object_count, xform_count, material_count, texture_count, background_index;
+    int32_t width, height, max_bounces;
+    DevCamera cam;
+};
+
+// ------------------------------------------------------------------ RNG -----------------
+// Keyed counter RNG: state = H(H(1984 + pixel) + n*PHI) for sample number n (1-based);
+// draw k (0-based) = H(state + (k+1)*PHI); H = lowbias32; uniform = ((x>>8)+1) * 2^-24,
+// in (0,1] like curand_uniform.  Replaces curand_init(1984+pixel, ...) (render.cuh:117).
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct Rng {
+    uint32_t state, draws;
+    __device__ __forceinline__ void init(int pixel_index, int sample_number) {
+        uint32_t s = lowbias32(1984u + (uint32_t)pixel_index);
+        state = lowbias32(s + (uint32_t)sample_number * 0x9E3779B9u);
+        draws = 0;
+    }
+    __device__ __forceinline__ float uniform() {
+        draws++;
+        uint32_t x = lowbias32(state + draws * 0x9E3779B9u);
+        return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);
+    }
+    __device__ __forceinline__ V3 range3(float lo, float hi) {       // vec3::random(min,max) vec3.cuh:191
+        float x = lo + (hi - lo) * uniform();
+        float y = lo + (hi - lo) * uniform();
+        float z = lo + (hi - lo) * uniform();
+        return v3(x, y, z);
+    }
+};
+
+__device__ __forceinline__ V3 random_unit_vector(Rng& r) {            // vec3.cuh:204-212
+    while (true) {
+        V3 p = r.range3(-1.0f, 1.0f);
+        float lensq = length_squared(p);
+        if (1e-30f < lensq && lensq <= 1.0f) return unit(p);
+    }
+}
+__device__ __forceinline__ V3 random_in_unit_sphere(Rng& r) {         // vec3.cuh:235-241
+    V3 p = r.range3(-1.0f, 1.0f);
+    while (length_squared(p) >= 1.0f) p = r.range3(-1.0f, 1.0f);
+    return p;
+}
+__device__ __forceinline__ void random_in_unit_disk(Rng& r, float& px, float& py) {   // vec3.cuh:249-255
+    do {
+        float a = r.uniform(), b = r.uniform();
+        px = 2.0f * a - 1.0f;
+        py = 2.0f * b - 1.0f;
+    } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
+}
+
+// ------------------------------------------------------------------ camera --------------
+struct Ray {
+    V3 o, d;
+    float time;
+};
+__device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rng& rng) {
+    V3 offset = rng.range3(-0.5f, 0.5f);            // sample_square: three draws, z unused (camera.cuh:93-96)
+    V3 on_plane = cam.llc + ((float)i + offset.x) * cam.du + ((float)j + offset.y) * cam.dv;
+    Ray r;
+    if (cam.type == 0) {                            // perspective_ray (camera.cuh:240-248)
+        if (cam.defocus_angle <= 0.0f) {
+            r.o = cam.center;
+        } else {
+            float px, py;
+            random_in_unit_disk(rng, px, py);
+            r.o = cam.center + (px * cam.defocus_u) + (py * cam.defocus_v);
+        }
+        r.d = on_plane - r.o;
+    } else {                                        // orthographic_ray (camera.cuh:259-266)
+        r.o = on_plane;
+        r.d = cam.w;
+    }
+    r.time = rng.uniform();
+    return r;
+}
+
+// ------------------------------------------------------------------ scene memory views --
+// Two views with the same interface: HBM (node-major records, served by L1/L2) and an LDS
+// copy (field-major, so that lanes on different nodes fall on different banks).
+struct SceneGlobal {
+    const float4* nodes;
+    const float4* prims;
+    const float* xforms;
+    __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[node * kNodeStrideGlobal + field]; }
+    __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[obj * kPrimQuads + q]; }
+    __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
+};
+struct SceneLds {
+    const float4* nodes;   // [7][node_count]
+    const float4* prims;   // [3][object_count]
+    const float* xforms;
+    int node_count, object_count;
+    __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[field * node_count + node]; }
+    __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[q * object_count + obj]; }
+    __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
+};
+
+// Per-lane traversal stack: entry e of lane l lives at base[e * stride + l] (conflict-free).
+struct LaneStack {
+    int* base;
+    int stride;
+    __device__ __forceinline__ void put(int e, int v) { base[e * stride] = v; }
+    __device__ __forceinline__ int get(int e) const { return base[e * stride]; }
+};
+
+struct Hit {
+    float t;     // closest accepted ray parameter
+    int obj;     // object index, -1 = miss
+    float bu, bv;  // triangle barycentrics
+};
+
+__device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3& oo, V3& od) {   // hittable.cuh:429-430
+    V3 anchor = v3(xf[9], xf[10], xf[11]), trans = v3(xf[12], xf[13], xf[14]);
+    oo = matvec(xf, o - anchor - trans) + anchor;
+    od = matvec(xf, d);
+}
+
+// hit_tri, hittable.cuh:314-335 (acceptance part).  Interval test is inclusive.
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax, float& t, float& bu, float& bv) {
+    V3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    if (fabsf(det) < 1e-8f) return false;
+    float inv_det = 1.0f / det;
+    V3 tvec = o - point;
+    float u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float tt = dot(e2, qvec) * inv_det;
+    if (!(tmin <= tt && tt <= tmax)) return false;
+    t = tt; bu = u; bv = v;
+    return true;
+}
+
+// hit_sphere, hittable.cuh:272-290 (acceptance part).  Interval test is exclusive.
+__device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd, float radius, float tmin, float tmax, float& t) {
+    V3 center = c0 + cd * time;
+    V3 oc = o - center;
+    float a = length_squared(d);
+    float h = dot(oc, d);
+    float c = length_squared(oc) - radius * radius;
+    float disc = h * h - a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float root = (-h - sq) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (-h + sq) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t = root;
+    return true;
+}
+
+template <class Mem>
+__device__ __forceinline__ bool prim_test(const Mem& S, int obj, const Ray& r, float tmin, float tmax, float& t, float& bu, float& bv) {
+    float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
+    int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
+    V3 o = r.o, d = r.d;
+    if (xf >= 0) to_object_space(S.xform(xf), r.o, r.d, o, d);
+    if (type == 2) return tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, tmax, t, bu, bv);
+    bu = 0.0f; bv = 0.0f;
+    return sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, t);
+}
+
+// Closest hit over the flat BVH4.  Visits the four slots of a node in storage order and
+// pops the most recently pushed child first, like bvh.cuh:387-419, so that candidates with
+// exactly equal t resolve to the same object as in the reference.
+template <class Mem>
+__device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, float tmax, LaneStack stk) {
+    // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
+    float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;
+    float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
+    float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
+    // field numbers of the near / far planes per axis (swap when the reciprocal is negative)
+    int nx = ix < 0.0f ? 3 : 0, fx = 3 - nx;
+    int ny = iy < 0.0f ? 4 : 1, fy = 5 - ny;
+    int nz = iz < 0.0f ? 5 : 2, fz = 7 - nz;
+
+    Hit best;
+    best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
+        float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
+        float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
+        float4 codef = S.node_field(node, 6);
+        const float nxs[4] = {bnx.x, bnx.y, bnx.z, bnx.w}, fxs[4] = {bfx.x, bfx.y, bfx.z, bfx.w};
+        const float nys[4] = {bny.x, bny.y, bny.z, bny.w}, fys[4] = {bfy.x, bfy.y, bfy.z, bfy.w};
+        const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
+        const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
+            float lo = fmaxf(tmin, t0), hi = fminf(best.t, t1);
+            t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
+            lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+            t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
+            lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+            if (hi < lo) continue;
+            int code = codes[i];
+            if (code >= 0) {
+                float t, bu, bv;
+                if (prim_test(S, code, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = code; best.bu = bu; best.bv = bv; }
+            } else if (code < -1) {
+                stk.put(sp++, -code - 2);
+            }
+        }
+        if (sp == 0) break;
+        node = stk.get(--sp);
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ textures ------------
+// Software tex2D: wrap addressing, bilinear, normalised coordinates, 8-bit -> [0,1]
+// (sampler state at texture.cuh:212-217).
+__device__ __forceinline__ int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+__device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, float out[4]) {
+    float x = (u - floorf(u)) * (float)img.width - 0.5f;
+    float y = (v - floorf(v)) * (float)img.height - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float ax = x - xf, ay = y - yf;
+    int x0 = wrapi((int)xf, img.width), x1 = wrapi((int)xf + 1, img.width);
+    int y0 = wrapi((int)yf, img.height), y1 = wrapi((int)yf + 1, img.height);
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (img.channels == 4) {
+        const uchar4* p = reinterpret_cast<const uchar4*>(img.pixels);
+        uchar4 a = p[(size_t)y0 * img.width + x0], b = p[(size_t)y0 * img.width + x1];
+        uchar4 c = p[(size_t)y1 * img.width + x0], d = p[(size_t)y1 * img.width + x1];
+        const float ta[4] = {(float)a.x, (float)a.y, (float)a.z, (float)a.w}, tb[4] = {(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+        const float tc[4] = {(float)c.x, (float)c.y, (float)c.z, (float)c.w}, td[4] = {(float)d.x, (float)d.y, (float)d.z, (float)d.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float t00 = ta[k] * (1.0f / 255.0f), t10 = tb[k] * (1.0f / 255.0f), t01 = tc[k] * (1.0f / 255.0f), t11 = td[k] * (1.0f / 255.0f);
+            out[k] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
+        }
+    } else {
+        const uint8_t* p = img.pixels;
+        float t00 = p[(size_t)y0 * img.width + x0] * (1.0f / 255.0f), t10 = p[(size_t)y0 * img.width + x1] * (1.0f / 255.0f);
+        float t01 = p[(size_t)y1 * img.width + x0] * (1.0f / 255.0f), t11 = p[(size_t)y1 * img.width + x1] * (1.0f / 255.0f);
+        out[0] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
+    }
+}
+
+// _texture::value (texture.cuh:313-324).  Checker recursion (texture.cuh:267-274) becomes a
+// walk down the texture indices; the host guarantees the texture graph is acyclic.
+__device__ __forceinline__ V3 texture_value(const DevScene& sc, int idx, float u, float v, V3 p) {
+    float4 t0 = sc.texs[idx * 2];
+    int type = __float_as_int(t0.x);
+    for (int guard = 0; type == 1 && guard < sc.texture_count; guard++) {
+        float4 t1 = sc.texs[idx * 2 + 1];
+        int xi = (int)floorf(t1.z * p.x), yi = (int)floorf(t1.z * p.y), zi = (int)floorf(t1.z * p.z);
+        bool even = (xi + yi + zi) % 2 == 0;
+        idx = even ? __float_as_int(t1.y) : __float_as_int(t1.x);
+        t0 = sc.texs[idx * 2];
+        type = __float_as_int(t0.x);
+    }
+    if (type == 0) return v3(t0.y, t0.z, t0.w);
+    if (type == 2) {
+        float4 t1 = sc.texs[idx * 2 + 1];
+        const DevImage img = sc.images[__float_as_int(t1.w)];
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        float px[4];
+        tex2d(img, u, v, px);
+        if (img.channels == 1) return v3(px[0], px[0], px[0]);
+        if (img.channels == 4) return v3(px[0], px[1], px[2]);
+        return v3(1.0f, 0.0f, 1.0f);
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------ hit record ----------
+struct Surface {
+    V3 p, normal;
+    float u, v;
+    bool front;
+    int mat;
+};
+
+// Rebuild the record of the closest hit: hit_tri / hit_sphere tail, object->world transform,
+// normal map (hittable.cuh:292-299, 338-356, 367-386, 438-444).
+__device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
+    const float4* pq = sc.prims + h.obj * kPrimQuads;
+    const float4* sq = sc.shade + h.obj * kShadeQuads;
+    float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
+    float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
+    int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
+    int normal_idx = __float_as_int(s1.w);
+    const float* X = sc.xforms + (xf >= 0 ? xf : 0) * kXformFloats;
+    V3 o = r.o, d = r.d;
+    if (xf >= 0) to_object_space(X, r.o, r.d, o, d);
+    Surface s;
+    s.mat = __float_as_int(s0.w);
+    V3 p = o + d * h.t;
+    V3 tangent = v3(0, 0, 0), bitangent = v3(0, 0, 0);
+    if (type == 2) {
+        float4 s3 = sq[3], s4 = sq[4], s5 = sq[5];
+        float w = 1.0f - h.bu - h.bv;
+        V3 n;
+        if (__float_as_int(s2.w)) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(s2.x, s2.y, s2.z));
+        else n = v3(s0.x, s0.y, s0.z);
+        s.front = dot(d, n) < 0.0f;
+        s.normal = s.front ? n : -n;
+        s.u = w * s3.x + h.bu * s3.z + h.bv * s4.x;
+        s.v = w * s3.y + h.bu * s3.w + h.bv * s4.y;
+        tangent = v3(s4.z, s4.w, s5.x);
+        bitangent = v3(s5.y, s5.z, s5.w);
+    } else {
+        V3 c0 = v3(q0.x, q0.y, q0.z), cd = v3(q1.x, q1.y, q1.z);
+        float radius = q0.w;
+        V3 center = c0 + cd * r.time;
+        V3 outward = (p - center) / radius;
+        s.front = dot(d, outward) < 0.0f;
+        s.normal = s.front ? outward : -outward;
+        float theta = acosf(-outward.y);                                 // get_sphere_uv
+        float phi = atan2f(-outward.z, outward.x) + kPi;
+        s.u = phi / (2 * kPi);
+        s.v = theta / kPi;
+        if (normal_idx >= 0) {                                           // get_tangent_bitangent: centre at rec.t
+            V3 local_p = p - (c0 + cd * h.t);
+            float ph = atan2f(-local_p.z, local_p.x) + kPi;
+            tangent = unit(v3(-radius * sinf(ph), 0.0f, radius * cosf(ph)));
+            bitangent = unit(cross(s.normal, tangent));
+        }
+    }
+    if (xf >= 0) {
+        V3 anchor = v3(X[9], X[10], X[11]), trans = v3(X[12], X[13], X[14]);
+        p = matvec(X + 15, p - anchor) + anchor;
+        p = p + trans;
+        s.normal = matvec(X + 15, s.normal);
+    }
+    s.p = p;
+    if (normal_idx >= 0) {                                               // apply_normal_map
+        float4 t1 = sc.texs[normal_idx * 2 + 1];
+        const DevImage img = sc.images[__float_as_int(t1.w)];
+        V3 pixel = v3(0.0f, 0.0f, 1.0f);
+        float px[4];
+        if (img.channels == 1) {
+            tex2d(img, s.u, s.v, px);
+            float value = px[0] * 2.0f - 1.0f;
+            pixel = v3(value, value, value);
+        } else if (img.channels == 4) {
+            tex2d(img, s.u, s.v, px);
+            pixel = v3(px[0] * 2.0f - 1.0f, px[1] * 2.0f - 1.0f, px[2] * 2.0f - 1.0f);
+        }
+        V3 wn = v3(tangent.x * pixel.x + bitangent.x * pixel.y + s.normal.x * pixel.z,
+                   tangent.y * pixel.x + bitangent.y * pixel.y + s.normal.y * pixel.z,
+                   tangent.z * pixel.x + bitangent.z * pixel.y + s.normal.z * pixel.z);
+        s.normal = unit(wn);
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------ materials -----------
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float ni_over_nt) {          // vec3.cuh:166-171
+    float cos_theta = fminf(dot(-uv, n), 1.0f);
+    V3 perp = ni_over_nt * (uv + cos_theta * n);
+    V3 parallel = -sqrtf(fabsf(1.0f - length_squared(perp))) * n;
+    return perp + parallel;
+}
+// (1-cos)^5 of the Schlick terms (material.cuh:152,186) as a multiplication chain.
+__device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+
+// material::scatter (material.cuh:359-372).  Returns false when the material does not
+// scatter (light, or a metal bounce that points into the surface).
+__device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const Surface& s, Rng& rng, V3& attenuation, Ray& out) {
+    float4 m0 = sc.mats[s.mat * 2];
+    int type = __float_as_int(m0.x);
+    out.time = in.time;
+    if (type == 0) {                                           // lambertian :290-297
+        V3 dir = s.normal + random_unit_vector(rng);
+        if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.normal;
+        out.o = s.p + s.normal * 0.001f;
+        out.d = dir;
+        attenuation = texture_value(sc, __float_as_int(m0.y), s.u, s.v, s.p);
+        return true;
+    }
+    if (type == 1) {                                           // metal :311-322
+        float4 m1 = sc.mats[s.mat * 2 + 1];
+        V3 unit_dir = unit(in.d);
+        V3 reflected = reflect(unit_dir, s.normal);
+        out.o = s.p;
+        out.d = reflected + m0.z * random_in_unit_sphere(rng);
+        float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
+        V3 albedo = v3(m1.x, m1.y, m1.z);
+        attenuation = albedo + (v3(1.0f, 1.0f, 1.0f) - albedo) * pow5(1.0f - cos_theta);
+        return dot(out.d, s.normal) > 0.0f;
+    }
+    if (type == 2) {                                           // dielectric :336-356
+        attenuation = v3(1.0f, 1.0f, 1.0f);
+        float ior = m0.w;
+        float ratio = s.front ? (1.0f / ior) : ior;
+        V3 unit_dir = unit(in.d);
+        float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool do_reflect = ratio * sin_theta > 1.0f;
+        if (!do_reflect) {                                     // the uniform is drawn only when refraction is possible
+            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            r0 = r0 * r0;
+            float reflectance = r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
+            do_reflect = reflectance > rng.uniform();
+        }
+        out.o = s.p;
+        out.d = do_reflect ? reflect(unit_dir, s.normal) : refract(unit_dir, s.normal, ratio);
+        return true;
+    }
+    return false;
+}
+// material::emit (material.cuh:375-381)
+__device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
+    float4 m0 = sc.mats[s.mat * 2];
+    if (__float_as_int(m0.x) == 3) return texture_value(sc, __float_as_int(m0.y), s.u, s.v, s.p);
+    return v3(0.0f, 0.0f, 0.0f);
+}
+// Environment lookup on a miss (render.cuh:77-82)
+__device__ __forceinline__ V3 environment(const DevScene& sc, V3 dir) {
+    float4 t0 = sc.texs[sc.background_index * 2];
+    if (__float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
+    V3 p = unit(dir);
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + kPi;
+    float u = phi / (2 * kPi);
+    float v = theta / kPi;
+    return texture_value(sc, sc.background_index, u, v, p);
+}
+
+}  // namespace crt
+
+#endif

@@ -1,0 +1,799 @@
+// Kernels and the device half of the C ABI (crt_scene_*, crt_buffers_*, crt_render*).
+//
+// Replaces render() / render_kernel (src/render.cuh:108-181) and the per-element scene
+// upload of scene::scene (src/scene.cuh:61-89).
+//
+// Kernel structure (fused mode, the default)
+//   render_fused   one lane owns one pixel of an 8x8 tile and walks the samples of its chunk.
+//                  Path regeneration keeps the wave full: a lane whose path ended starts its
+//                  next sample in the same iteration in which the other lanes trace their next
+//                  bounce, so divergence over path LENGTH (1..max_bounces) never idles lanes;
+//                  the only divergence left is inside one traversal / one shading step.
+//                  Sums of the six passes stay in registers; nothing but the final 14 floats
+//                  per (pixel, chunk) touches HBM.
+//   resolve_passes adds the chunk sums in chunk order, folds them into the running mean of
+//                  the pass buffers ((old*done + sum) / (done + n), which for n = 1 is the
+//                  reference's update at render.cuh:147-152) and writes the reference layout.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "crt_internal.h"
+#include "pt_device.h"
+
+namespace crt {
+
+constexpr int kBlock = 256;          // 4 waves; one 8x8 pixel tile per wave
+constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
+
+struct RenderArgs {
+    DevScene sc;
+    float* partial;                  // [chunks][14][pix_padded]  chunk sums, tile-major pixels
+    unsigned long long* ray_counter;
+    int tiles_x, tiles_y, ntiles, pix_padded;
+    int first_sample, samples, chunk_size;
+    int lds_scene_bytes;
+};
+
+__device__ __forceinline__ int xcd_remap(int block, int nblocks) {
+    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
+    // so that neighbouring tiles (which walk the same BVH nodes) share one L2.  Bijective for
+    // any nblocks.
+    int q = nblocks >> 3, r = nblocks & 7, x = block & 7, k = block >> 3;
+    int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return start + k;
+}
+
+template <bool LDS>
+struct MemOf;
+template <>
+struct MemOf<false> { using type = SceneGlobal; };
+template <>
+struct MemOf<true> { using type = SceneLds; };
+
+template <bool LDS>
+__device__ __forceinline__ typename MemOf<LDS>::type make_mem(const DevScene& sc, float4* lds_scene) {
+    if constexpr (LDS) {
+        // cooperative copy HBM -> LDS, transposing nodes and primitives to field-major
+        const int nn = sc.node_count, no = sc.object_count;
+        float4* ln = lds_scene;
+        float4* lp = ln + kNodeFields * nn;
+        float* lx = reinterpret_cast<float*>(lp + kPrimQuads * no);
+        for (int i = threadIdx.x; i < nn * kNodeFields; i += kBlock) {
+            int node = i / kNodeFields, f = i - node * kNodeFields;
+            ln[f * nn + node] = sc.nodes[node * kNodeStrideGlobal + f];
+        }
+        for (int i = threadIdx.x; i < no * kPrimQuads; i += kBlock) {
+            int obj = i / kPrimQuads, q = i - obj * kPrimQuads;
+            lp[q * no + obj] = sc.prims[i];
+        }
+        for (int i = threadIdx.x; i < sc.xform_count * kXformFloats; i += kBlock) lx[i] = sc.xforms[i];
+        __syncthreads();
+        SceneLds m;
+        m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no;
+        return m;
+    } else {
+        SceneGlobal m;
+        m.nodes = sc.nodes; m.prims = sc.prims; m.xforms = sc.xforms;
+        return m;
+    }
+}
+
+template <int STACK, bool LDS>
+__global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
+    extern __shared__ float4 smem[];
+    int* stack_mem = reinterpret_cast<int*>(smem);
+    float4* lds_scene = smem + (STACK * kBlock) / 4;
+    const DevScene& sc = A.sc;
+    auto S = make_mem<LDS>(sc, lds_scene);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    if (tile >= A.ntiles) return;
+    const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
+    const int pi = tx * 8 + (lane & 7), pj = ty * 8 + (lane >> 3);
+    const bool valid = pi < sc.width && pj < sc.height;
+    const int pixel_index = pj * sc.width + pi;
+    LaneStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.stride = kBlock;
+
+    const int chunk = blockIdx.y;
+    int s = A.first_sample + chunk * A.chunk_size;                  // samples already started
+    const int s_end = min(s + A.chunk_size, A.first_sample + A.samples);
+
+    V3 sum_col = v3(0, 0, 0), sum_alb = v3(0, 0, 0), sum_emi = v3(0, 0, 0), sum_nrm = v3(0, 0, 0);
+    float sum_depth = 0.0f, sum_opacity = 0.0f;
+    unsigned int rays = 0;
+
+    bool alive = false;
+    Ray ray;
+    ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
+    V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
+    int bounces = 0;
+    Rng rng;
+    rng.state = 0; rng.draws = 0;
+
+    while (true) {
+        if (!alive && valid && s < s_end) {                          // regenerate: next sample of this pixel
+            s++;
+            rng.init(pixel_index, s);
+            ray = camera_ray(sc.cam, pi, pj, rng);
+            throughput = v3(1, 1, 1);
+            pend_albedo = v3(0, 0, 0);
+            bounces = 0;
+            alive = sc.max_bounces > 0;                              // render.cuh:44 with max_bounces == 0
+        }
+        if (!__any(alive)) break;
+        if (alive) {
+            rays++;
+            Hit h = traverse(S, ray, 0.001f, INFINITY, stk);        // render.cuh:47
+            if (h.obj >= 0) {
+                Surface sf = make_surface(sc, ray, h);
+                V3 attenuation;
+                Ray next;
+                if (scatter(sc, ray, sf, rng, attenuation, next)) {  // render.cuh:52-61
+                    if (bounces == 0) {
+                        pend_albedo = attenuation;
+                        sum_nrm = sum_nrm + unit(sf.normal);
+                        sum_depth += h.t * length(ray.d);
+                        sum_opacity += 1.0f;
+                    }
+                    throughput = throughput * attenuation;
+                    ray = next;
+                    bounces++;
+                    if (bounces >= sc.max_bounces) alive = false;   // exhausted: col = albedo = 0 (render.cuh:96-97)
+                } else {                                             // render.cuh:64-74
+                    V3 emitted = emit(sc, sf);
+                    sum_col = sum_col + throughput * emitted;
+                    if (bounces == 0) {
+                        sum_alb = sum_alb + emitted;
+                        sum_emi = sum_emi + emitted;
+                        sum_nrm = sum_nrm + unit(sf.normal);
+                        sum_depth += h.t * length(ray.d);
+                        sum_opacity += 1.0f;
+                    } else {
+                        sum_alb = sum_alb + pend_albedo;
+                    }
+                    alive = false;
+                }
+            } else {                                                 // render.cuh:76-91
+                V3 c = throughput * environment(sc, ray.d);
+                sum_col = sum_col + c;
+                if (bounces == 0) {
+                    sum_alb = sum_alb + c;
+                    sum_depth += __builtin_nanf("");
+                } else {
+                    sum_alb = sum_alb + pend_albedo;
+                }
+                alive = false;
+            }
+        }
+    }
+
+    float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * 64 + lane;
+    const size_t ps = A.pix_padded;
+    out[0 * ps] = sum_col.x; out[1 * ps] = sum_col.y; out[2 * ps] = sum_col.z;
+    out[3 * ps] = sum_alb.x; out[4 * ps] = sum_alb.y; out[5 * ps] = sum_alb.z;
+    out[6 * ps] = sum_emi.x; out[7 * ps] = sum_emi.y; out[8 * ps] = sum_emi.z;
+    out[9 * ps] = sum_nrm.x; out[10 * ps] = sum_nrm.y; out[11 * ps] = sum_nrm.z;
+    out[12 * ps] = sum_depth; out[13 * ps] = sum_opacity;
+
+    // one ray-count atomic per wave
+    unsigned int total = rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (lane == 0) atomicAdd(A.ray_counter, (unsigned long long)total);
+}
+
+struct ResolveArgs {
+    const float* partial;
+    float *color, *albedo, *emission, *normal, *depth, *opacity;
+    int width, height, tiles_x, ntiles, pix_padded, chunks;
+    float done, count;     // samples already in the buffers / samples summed now
+    int fold;              // 0: overwrite with sum/count, 1: (old*done + sum)/(done+count)
+};
+
+__global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= R.pix_padded) return;
+    const int tile = t >> 6, lane = t & 63;
+    const int pi = (tile % R.tiles_x) * 8 + (lane & 7), pj = (tile / R.tiles_x) * 8 + (lane >> 3);
+    if (pi >= R.width || pj >= R.height) return;
+    const int pixel = pj * R.width + pi;
+    float v[kPasses];
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) {
+        float acc = R.partial[(size_t)k * R.pix_padded + t];
+        for (int c = 1; c < R.chunks; c++) acc += R.partial[((size_t)c * kPasses + k) * R.pix_padded + t];
+        v[k] = acc;
+    }
+    float* dst[kPasses] = {R.color + 3 * pixel, R.color + 3 * pixel + 1, R.color + 3 * pixel + 2,
+                           R.albedo + 3 * pixel, R.albedo + 3 * pixel + 1, R.albedo + 3 * pixel + 2,
+                           R.emission + 3 * pixel, R.emission + 3 * pixel + 1, R.emission + 3 * pixel + 2,
+                           R.normal + 3 * pixel, R.normal + 3 * pixel + 1, R.normal + 3 * pixel + 2,
+                           R.depth + pixel, R.opacity + pixel};
+    const float total = R.done + R.count;
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) {
+        float x = R.fold ? (*dst[k] * R.done + v[k]) / total : v[k] / R.count;
+        *dst[k] = x;
+    }
+}
+
+// Bounce-0 closest hit per pixel for the parity tables.
+struct PrimaryArgs {
+    DevScene sc;
+    int sample;
+    int32_t* obj;
+    float *t, *u, *v;
+    int32_t* front;
+};
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
+    __shared__ int stack_mem[STACK * kBlock];
+    const DevScene& sc = A.sc;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= sc.width * sc.height) return;
+    const int pi = idx % sc.width, pj = idx / sc.width;
+    SceneGlobal S;
+    S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms;
+    LaneStack stk;
+    stk.base = stack_mem + threadIdx.x;
+    stk.stride = kBlock;
+    Rng rng;
+    rng.init(idx, A.sample);
+    Ray ray = camera_ray(sc.cam, pi, pj, rng);
+    Hit h = traverse(S, ray, 0.001f, INFINITY, stk);
+    A.obj[idx] = h.obj;
+    if (h.obj >= 0) {
+        Surface sf = make_surface(sc, ray, h);
+        A.t[idx] = h.t; A.u[idx] = sf.u; A.v[idx] = sf.v; A.front[idx] = sf.front ? 1 : 0;
+    } else {
+        A.t[idx] = INFINITY; A.u[idx] = 0.0f; A.v[idx] = 0.0f; A.front[idx] = 0;
+    }
+}
+
+}  // namespace crt
+
+// ====================================================================== host side =======
+using namespace crt;
+
+struct crt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    void* blob = nullptr;            // nodes | prims | shade | xforms | mats | texs | images
+    std::vector<void*> image_mem;
+    DevScene dev = {};
+    crt_render_info render = {};
+    int stack_entries = 8;
+    bool lds_scene = false;
+    int lds_scene_bytes = 0;
+    int mode = 0;
+    float* partial = nullptr;
+    size_t partial_bytes = 0;
+    unsigned long long* ray_counter = nullptr;
+    bool launched = false;
+};
+
+struct crt_buffers {
+    int width = 0, height = 0;
+    float* base = nullptr;           // 14*W*H floats
+    bool owned = false;
+    float* color() const { return base; }
+    float* albedo() const { return base + 3 * (size_t)width * height; }
+    float* emission() const { return base + 6 * (size_t)width * height; }
+    float* normal() const { return base + 9 * (size_t)width * height; }
+    float* depth() const { return base + 12 * (size_t)width * height; }
+    float* opacity() const { return base + 13 * (size_t)width * height; }
+};
+
+namespace {
+
+#define CRT_HIP(call)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return crt::set_error(CRT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+bool identity9(const float* m) {
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; i++)
+        if (m[i] != I[i]) return false;
+    return true;
+}
+bool zero3(const float* v) { return v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f; }
+
+float as_float(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+// Checks every index the kernels will follow, so that no launch can read out of bounds.
+int validate(const crt_scene_desc* d, int& bvh_depth, std::string& why) {
+    auto bad = [&](const std::string& s) { why = s; return CRT_ERR_INVALID; };
+    if (d->object_count < 0 || d->material_count < 0 || d->texture_count <= 0) return bad("counts must be non-negative and there must be a background texture");
+    if (d->object_count && !d->objects) return bad("objects is null");
+    if (d->material_count && !d->materials) return bad("materials is null");
+    if (!d->textures) return bad("textures is null");
+    if (d->background_index < 0 || d->background_index >= d->texture_count) return bad("background_index out of range");
+    if (d->render.image_width <= 0 || d->render.image_height <= 0) return bad("image size must be positive");
+    if ((long long)d->render.image_width * d->render.image_height > (1ll << 30)) return bad("image too large");
+    if (d->render.max_bounces < 0) return bad("max_bounces must be >= 0");
+    if (d->camera.type != CRT_CAM_PERSPECTIVE && d->camera.type != CRT_CAM_ORTHOGRAPHIC) return bad("unknown camera type");
+    for (int i = 0; i < d->texture_count; i++) {
+        const crt_texture& t = d->textures[i];
+        if (t.type == CRT_TEX_CHECKER) {
+            // children must come earlier in the list: this is what the loader produces and it
+            // makes the texture graph acyclic (the device walks it with a bounded loop)
+            if (t.odd_idx < 0 || t.odd_idx >= i || t.even_idx < 0 || t.even_idx >= i) return bad("checker texture " + std::to_string(i) + " must reference earlier textures");
+        } else if (t.type == CRT_TEX_IMAGE) {
+            if (t.width <= 0 || t.height <= 0 || (t.channels != 1 && t.channels != 4) || !t.pixels) return bad("image texture " + std::to_string(i) + " is invalid (channels must be 1 or 4)");
+        } else if (t.type != CRT_TEX_SOLID_COLOR) return bad("unknown texture type");
+    }
+    for (int i = 0; i < d->material_count; i++) {
+        const crt_material& m = d->materials[i];
+        if (m.type < CRT_MAT_LAMBERTIAN || m.type > CRT_MAT_DIFFUSE_LIGHT) return bad("unknown material type");
+        if ((m.type == CRT_MAT_LAMBERTIAN || m.type == CRT_MAT_DIFFUSE_LIGHT) && (m.tex_idx < 0 || m.tex_idx >= d->texture_count))
+            return bad("material " + std::to_string(i) + " texture index out of range");
+    }
+    for (int i = 0; i < d->object_count; i++) {
+        const crt_object& o = d->objects[i];
+        if (o.type != CRT_OBJ_SPHERE && o.type != CRT_OBJ_TRI) return bad("object " + std::to_string(i) + " has unknown type");
+        if (o.mat_idx < 0 || o.mat_idx >= d->material_count) return bad("object " + std::to_string(i) + " material index out of range");
+        if (o.normal_idx >= d->texture_count) return bad("object " + std::to_string(i) + " normal texture index out of range");
+        if (o.normal_idx >= 0 && d->textures[o.normal_idx].type != CRT_TEX_IMAGE) return bad("object " + std::to_string(i) + " normal map must be an image texture");
+    }
+    const crt_bvh4& b = d->bvh;
+    if (b.slot_count < 4 || b.slot_count % 4 != 0 || !b.min_bounds || !b.max_bounds || !b.children || !b.object_index) return bad("BVH arrays missing");
+    const int nodes = b.slot_count / 4;
+    // every node except the root must be referenced exactly once and only by a lower-numbered
+    // node (pre-order numbering), which also rules out cycles
+    std::vector<int> depth(nodes, 0);
+    std::vector<uint8_t> seen(nodes, 0);
+    depth[0] = 1;
+    seen[0] = 1;
+    bvh_depth = 1;
+    for (int n = 0; n < nodes; n++) {
+        if (!seen[n]) return bad("BVH node " + std::to_string(n) + " is unreachable or referenced before its parent");
+        for (int i = 0; i < 4; i++) {
+            int s = n * 4 + i;
+            int c = b.children[s], o = b.object_index[s];
+            if (o >= d->object_count || o < -1) return bad("BVH object index out of range");
+            if (c < -1 || c >= nodes) return bad("BVH child index out of range");
+            if (c >= 0) {
+                if (c <= n || seen[c]) return bad("BVH child links must form a pre-order tree");
+                seen[c] = 1;
+                depth[c] = depth[n] + 1;
+                bvh_depth = std::max(bvh_depth, depth[c]);
+            }
+        }
+    }
+    return CRT_OK;
+}
+
+struct Blob {
+    std::vector<uint8_t> bytes;
+    size_t add(const void* p, size_t n) {
+        size_t off = (bytes.size() + 255) & ~size_t(255);
+        bytes.resize(off + n);
+        if (n) std::memcpy(bytes.data() + off, p, n);
+        return off;
+    }
+};
+
+void free_scene(crt_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->stream) (void)hipStreamSynchronize(sc->stream);
+    for (void* p : sc->image_mem) (void)hipFree(p);
+    if (sc->blob) (void)hipFree(sc->blob);
+    if (sc->partial) (void)hipFree(sc->partial);
+    if (sc->ray_counter) (void)hipFree(sc->ray_counter);
+    if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
+    if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    delete sc;
+}
+
+template <int STACK>
+int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
+    size_t lds = (size_t)STACK * kBlock * sizeof(int) + (sc->lds_scene ? (size_t)sc->lds_scene_bytes : 0);
+    if (sc->lds_scene) {
+        hipLaunchKernelGGL((render_fused<STACK, true>), grid, dim3(kBlock), lds, sc->stream, A);
+    } else {
+        hipLaunchKernelGGL((render_fused<STACK, false>), grid, dim3(kBlock), lds, sc->stream, A);
+    }
+    CRT_HIP(hipGetLastError());
+    return CRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crt_device_count(int* count) {
+    crt::clear_error();
+    if (!count) return crt::set_error(CRT_ERR_INVALID, "crt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return crt::set_error(CRT_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return CRT_OK;
+}
+
+int crt_set_device(int device) {
+    crt::clear_error();
+    CRT_HIP(hipSetDevice(device));
+    return CRT_OK;
+}
+
+int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
+    crt::clear_error();
+    if (!d || !out) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: null argument");
+    int bvh_depth = 0;
+    std::string why;
+    if (validate(d, bvh_depth, why) != CRT_OK) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: " + why);
+    // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
+    const int need = 3 * (bvh_depth - 1) + 1;
+    int stack_entries = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : need <= 64 ? 64 : 0;
+    if (!stack_entries) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: BVH deeper than 22 levels");
+
+    const int nodes = d->bvh.slot_count / 4;
+    // ---- repack: nodes (node-major, 8 float4), prims, shade, xforms (deduplicated), mats, texs
+    std::vector<float> node_rec((size_t)nodes * kNodeStrideGlobal * 4, 0.0f);
+    for (int n = 0; n < nodes; n++) {
+        float* rec = &node_rec[(size_t)n * kNodeStrideGlobal * 4];
+        for (int i = 0; i < 4; i++) {
+            int s = n * 4 + i;
+            for (int a = 0; a < 3; a++) {
+                rec[(a)*4 + i] = d->bvh.min_bounds[3 * s + a];
+                rec[(3 + a) * 4 + i] = d->bvh.max_bounds[3 * s + a];
+            }
+            int o = d->bvh.object_index[s], c = d->bvh.children[s];
+            int32_t code = o >= 0 ? o : (c >= 0 ? -c - 2 : -1);
+            rec[6 * 4 + i] = as_float(code);
+        }
+    }
+    std::vector<float> xforms;
+    std::vector<float> prim_rec((size_t)d->object_count * kPrimQuads * 4, 0.0f), shade_rec((size_t)d->object_count * kShadeQuads * 4, 0.0f);
+    for (int i = 0; i < d->object_count; i++) {
+        const crt_object& o = d->objects[i];
+        int xf = -1;
+        if (!(identity9(o.rotation) && identity9(o.rotation_inv) && zero3(o.anchor) && zero3(o.translation))) {
+            float rec[kXformFloats];
+            std::memcpy(rec, o.rotation_inv, 36);
+            std::memcpy(rec + 9, o.anchor, 12);
+            std::memcpy(rec + 12, o.translation, 12);
+            std::memcpy(rec + 15, o.rotation, 36);
+            const int count = (int)(xforms.size() / kXformFloats);
+            for (int k = count - 1; k >= 0 && k >= count - 64; k--)     // objects of one group sit next to each other
+                if (!std::memcmp(&xforms[(size_t)k * kXformFloats], rec, sizeof(rec))) { xf = k; break; }
+            if (xf < 0) { xf = count; xforms.insert(xforms.end(), rec, rec + kXformFloats); }
+        }
+        float* p = &prim_rec[(size_t)i * kPrimQuads * 4];
+        if (o.type == CRT_OBJ_TRI) {
+            p[0] = o.p0[0]; p[1] = o.p0[1]; p[2] = o.p0[2]; p[3] = o.p1[0];
+            p[4] = o.p1[1]; p[5] = o.p1[2]; p[6] = o.p2[0]; p[7] = o.p2[1];
+            p[8] = o.p2[2];
+        } else {
+            p[0] = o.p0[0]; p[1] = o.p0[1]; p[2] = o.p0[2]; p[3] = o.p2[0];
+            p[4] = o.p1[0]; p[5] = o.p1[1]; p[6] = o.p1[2];
+        }
+        p[9] = as_float(xf); p[10] = as_float(o.type);
+        float* s = &shade_rec[(size_t)i * kShadeQuads * 4];
+        s[0] = o.n0[0]; s[1] = o.n0[1]; s[2] = o.n0[2]; s[3] = as_float(o.mat_idx);
+        s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2]; s[7] = as_float(o.normal_idx);
+        s[8] = o.n2[0]; s[9] = o.n2[1]; s[10] = o.n2[2]; s[11] = as_float(o.shade_smooth ? 1 : 0);
+        s[12] = o.uv0[0]; s[13] = o.uv0[1]; s[14] = o.uv1[0]; s[15] = o.uv1[1];
+        s[16] = o.uv2[0]; s[17] = o.uv2[1]; s[18] = o.tangent[0]; s[19] = o.tangent[1];
+        s[20] = o.tangent[2]; s[21] = o.bitangent[0]; s[22] = o.bitangent[1]; s[23] = o.bitangent[2];
+    }
+    if (xforms.empty()) xforms.assign(kXformFloats, 0.0f);
+    std::vector<float> mat_rec((size_t)std::max(1, d->material_count) * 8, 0.0f);
+    for (int i = 0; i < d->material_count; i++) {
+        const crt_material& m = d->materials[i];
+        float* r = &mat_rec[(size_t)i * 8];
+        r[0] = as_float(m.type); r[1] = as_float(m.tex_idx); r[2] = m.fuzz; r[3] = m.ior;
+        r[4] = m.albedo[0]; r[5] = m.albedo[1]; r[6] = m.albedo[2];
+    }
+    std::vector<float> tex_rec((size_t)d->texture_count * 8, 0.0f);
+    std::vector<DevImage> images;
+    std::vector<const crt_texture*> image_src;
+    for (int i = 0; i < d->texture_count; i++) {
+        const crt_texture& t = d->textures[i];
+        float* r = &tex_rec[(size_t)i * 8];
+        r[0] = as_float(t.type); r[1] = t.color[0]; r[2] = t.color[1]; r[3] = t.color[2];
+        r[4] = as_float(t.odd_idx); r[5] = as_float(t.even_idx); r[6] = t.inv_scale; r[7] = as_float(-1);
+        if (t.type == CRT_TEX_IMAGE) {
+            r[7] = as_float((int)images.size());
+            DevImage im = {nullptr, t.width, t.height, t.channels, 0};
+            images.push_back(im);
+            image_src.push_back(&t);
+        }
+    }
+
+    crt_scene* sc = new crt_scene();
+    if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; return crt::set_error(CRT_ERR_DEVICE, "crt_scene_create: no HIP device"); }
+#define CRT_HIP_OR_FREE(call)                                                                                          \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) { free_scene(sc); return crt::set_error(CRT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    CRT_HIP_OR_FREE(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_start));
+    CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_stop));
+    for (size_t k = 0; k < images.size(); k++) {
+        void* mem = nullptr;
+        size_t bytes = (size_t)images[k].width * images[k].height * images[k].channels;
+        CRT_HIP_OR_FREE(hipMalloc(&mem, bytes));
+        sc->image_mem.push_back(mem);
+        CRT_HIP_OR_FREE(hipMemcpy(mem, image_src[k]->pixels, bytes, hipMemcpyHostToDevice));
+        images[k].pixels = static_cast<const uint8_t*>(mem);
+    }
+    if (images.empty()) images.push_back(DevImage{nullptr, 0, 0, 0, 0});
+    Blob blob;
+    size_t off_nodes = blob.add(node_rec.data(), node_rec.size() * 4);
+    size_t off_prims = blob.add(prim_rec.data(), prim_rec.size() * 4);
+    size_t off_shade = blob.add(shade_rec.data(), shade_rec.size() * 4);
+    size_t off_xf = blob.add(xforms.data(), xforms.size() * 4);
+    size_t off_mats = blob.add(mat_rec.data(), mat_rec.size() * 4);
+    size_t off_texs = blob.add(tex_rec.data(), tex_rec.size() * 4);
+    size_t off_img = blob.add(images.data(), images.size() * sizeof(DevImage));
+    blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
+    CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
+    CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
+    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, sizeof(unsigned long long)));
+#undef CRT_HIP_OR_FREE
+    uint8_t* base = static_cast<uint8_t*>(sc->blob);
+    DevScene& D = sc->dev;
+    D.nodes = reinterpret_cast<const float4*>(base + off_nodes);
+    D.prims = reinterpret_cast<const float4*>(base + off_prims);
+    D.shade = reinterpret_cast<const float4*>(base + off_shade);
+    D.xforms = reinterpret_cast<const float*>(base + off_xf);
+    D.mats = reinterpret_cast<const float4*>(base + off_mats);
+    D.texs = reinterpret_cast<const float4*>(base + off_texs);
+    D.images = reinterpret_cast<const DevImage*>(base + off_img);
+    D.node_count = nodes;
+    D.object_count = d->object_count;
+    D.xform_count = (int)(xforms.size() / kXformFloats);
+    D.material_count = d->material_count;
+    D.texture_count = d->texture_count;
+    D.background_index = d->background_index;
+    D.width = d->render.image_width;
+    D.height = d->render.image_height;
+    D.max_bounces = d->render.max_bounces;
+    const crt_camera& c = d->camera;
+    D.cam.type = c.type;
+    D.cam.defocus_angle = c.defocus_angle;
+    D.cam.center = v3(c.center); D.cam.llc = v3(c.lower_left_corner);
+    D.cam.du = v3(c.pixel_delta_u); D.cam.dv = v3(c.pixel_delta_v); D.cam.w = v3(c.w);
+    D.cam.defocus_u = v3(c.defocus_disk_u); D.cam.defocus_v = v3(c.defocus_disk_v);
+    sc->render = d->render;
+    sc->stack_entries = stack_entries;
+    sc->lds_scene_bytes = (int)(((size_t)nodes * kNodeFields + (size_t)d->object_count * kPrimQuads) * 16 + xforms.size() * 4);
+    // keep a block (stack + scene copy) under 40 KB so that four blocks still fit a CU
+    sc->lds_scene = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 <= 40 * 1024;
+    if (const char* e = std::getenv("CRT_LDS_SCENE")) sc->lds_scene = sc->lds_scene && std::atoi(e) != 0;
+    *out = sc;
+    return CRT_OK;
+}
+
+void crt_scene_destroy(crt_scene* sc) { free_scene(sc); }
+
+int crt_scene_set_mode(crt_scene* sc, int mode) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_set_mode: null scene");
+    if (mode != 0) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_set_mode: only mode 0 (fused) is available");
+    sc->mode = mode;
+    return CRT_OK;
+}
+
+void* crt_scene_stream(crt_scene* sc) { return sc ? (void*)sc->stream : nullptr; }
+
+int crt_buffers_create(int width, int height, crt_buffers** out) {
+    crt::clear_error();
+    if (!out || width <= 0 || height <= 0) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_create: bad arguments");
+    void* mem = nullptr;
+    size_t bytes = (size_t)kPasses * width * height * sizeof(float);
+    CRT_HIP(hipMalloc(&mem, bytes));
+    hipError_t e = hipMemset(mem, 0, bytes);
+    if (e != hipSuccess) { (void)hipFree(mem); return crt::set_error(CRT_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(e)); }
+    crt_buffers* b = new crt_buffers();
+    b->width = width; b->height = height; b->base = static_cast<float*>(mem); b->owned = true;
+    *out = b;
+    return CRT_OK;
+}
+
+int crt_buffers_wrap(int width, int height, void* device_ptr, crt_buffers** out) {
+    crt::clear_error();
+    if (!out || !device_ptr || width <= 0 || height <= 0) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_wrap: bad arguments");
+    if (reinterpret_cast<uintptr_t>(device_ptr) % 16) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_wrap: pointer must be 16-byte aligned");
+    crt_buffers* b = new crt_buffers();
+    b->width = width; b->height = height; b->base = static_cast<float*>(device_ptr); b->owned = false;
+    *out = b;
+    return CRT_OK;
+}
+
+void crt_buffers_destroy(crt_buffers* b) {
+    if (!b) return;
+    if (b->owned && b->base) (void)hipFree(b->base);
+    delete b;
+}
+
+int crt_buffers_download(const crt_buffers* b, float* color, float* albedo, float* emission, float* normal, float* depth, float* opacity) {
+    crt::clear_error();
+    if (!b) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_download: null buffers");
+    const size_t n = (size_t)b->width * b->height;
+    CRT_HIP(hipDeviceSynchronize());
+    if (color) CRT_HIP(hipMemcpy(color, b->color(), n * 12, hipMemcpyDeviceToHost));
+    if (albedo) CRT_HIP(hipMemcpy(albedo, b->albedo(), n * 12, hipMemcpyDeviceToHost));
+    if (emission) CRT_HIP(hipMemcpy(emission, b->emission(), n * 12, hipMemcpyDeviceToHost));
+    if (normal) CRT_HIP(hipMemcpy(normal, b->normal(), n * 12, hipMemcpyDeviceToHost));
+    if (depth) CRT_HIP(hipMemcpy(depth, b->depth(), n * 4, hipMemcpyDeviceToHost));
+    if (opacity) CRT_HIP(hipMemcpy(opacity, b->opacity(), n * 4, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_buffers_upload(crt_buffers* b, const float* color, const float* albedo, const float* emission, const float* normal, const float* depth, const float* opacity) {
+    crt::clear_error();
+    if (!b) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_upload: null buffers");
+    const size_t n = (size_t)b->width * b->height;
+    CRT_HIP(hipDeviceSynchronize());
+    if (color) CRT_HIP(hipMemcpy(b->color(), color, n * 12, hipMemcpyHostToDevice));
+    if (albedo) CRT_HIP(hipMemcpy(b->albedo(), albedo, n * 12, hipMemcpyHostToDevice));
+    if (emission) CRT_HIP(hipMemcpy(b->emission(), emission, n * 12, hipMemcpyHostToDevice));
+    if (normal) CRT_HIP(hipMemcpy(b->normal(), normal, n * 12, hipMemcpyHostToDevice));
+    if (depth) CRT_HIP(hipMemcpy(b->depth(), depth, n * 4, hipMemcpyHostToDevice));
+    if (opacity) CRT_HIP(hipMemcpy(b->opacity(), opacity, n * 4, hipMemcpyHostToDevice));
+    return CRT_OK;
+}
+
+int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done) {
+    crt::clear_error();
+    if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: null argument");
+    if (buf->width != sc->dev.width || buf->height != sc->dev.height) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: buffer size does not match the scene");
+    if (samples <= 0 || first_sample < 0) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: samples must be positive");
+    if (sc->launched) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: a render is already in flight on this scene");
+    CRT_HIP(hipSetDevice(sc->device));
+    RenderArgs A;
+    A.sc = sc->dev;
+    A.tiles_x = (sc->dev.width + 7) / 8;
+    A.tiles_y = (sc->dev.height + 7) / 8;
+    A.ntiles = A.tiles_x * A.tiles_y;
+    A.pix_padded = A.ntiles * 64;
+    // Split the samples into chunks so that the grid has several times more waves than the
+    // chip holds (256 CUs x 16-32 waves); the tail of the launch then costs one chunk, not one
+    // whole pixel.
+    int target_waves = 65536;
+    if (const char* e = std::getenv("CRT_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
+    int chunks = std::min(samples, std::max(1, (target_waves + A.ntiles - 1) / A.ntiles));
+    A.chunk_size = (samples + chunks - 1) / chunks;
+    chunks = (samples + A.chunk_size - 1) / A.chunk_size;
+    A.first_sample = first_sample;
+    A.samples = samples;
+    A.lds_scene_bytes = sc->lds_scene_bytes;
+    size_t need = (size_t)chunks * kPasses * A.pix_padded * sizeof(float);
+    if (need > sc->partial_bytes) {
+        if (sc->partial) CRT_HIP(hipFree(sc->partial));
+        sc->partial = nullptr;
+        sc->partial_bytes = 0;
+        CRT_HIP(hipMalloc((void**)&sc->partial, need));
+        sc->partial_bytes = need;
+    }
+    A.partial = sc->partial;
+    A.ray_counter = sc->ray_counter;
+    CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, sizeof(unsigned long long), sc->stream));
+    dim3 grid((A.ntiles + (kBlock / 64) - 1) / (kBlock / 64), chunks);
+    CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
+    int rc;
+    switch (sc->stack_entries) {
+    case 8: rc = launch_fused<8>(sc, A, grid); break;
+    case 16: rc = launch_fused<16>(sc, A, grid); break;
+    case 32: rc = launch_fused<32>(sc, A, grid); break;
+    default: rc = launch_fused<64>(sc, A, grid); break;
+    }
+    if (rc != CRT_OK) return rc;
+    ResolveArgs R;
+    R.partial = sc->partial;
+    R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
+    R.depth = buf->depth(); R.opacity = buf->opacity();
+    R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = A.tiles_x; R.ntiles = A.ntiles; R.pix_padded = A.pix_padded;
+    R.chunks = chunks;
+    R.done = (float)fold_done;
+    R.count = (float)samples;
+    R.fold = fold_done > 0 ? 1 : 0;
+    hipLaunchKernelGGL(resolve_passes, dim3((A.pix_padded + kBlock - 1) / kBlock), dim3(kBlock), 0, sc->stream, R);
+    CRT_HIP(hipGetLastError());
+    CRT_HIP(hipEventRecord(sc->ev_stop, sc->stream));
+    sc->launched = true;
+    return CRT_OK;
+}
+
+int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_finish: null scene");
+    if (!sc->launched) return crt::set_error(CRT_ERR_INVALID, "crt_render_finish: nothing was launched");
+    sc->launched = false;
+    CRT_HIP(hipStreamSynchronize(sc->stream));
+    if (kernel_ms_out) {
+        float ms = 0.0f;
+        CRT_HIP(hipEventElapsedTime(&ms, sc->ev_start, sc->ev_stop));
+        *kernel_ms_out = ms;
+    }
+    if (rays_out) {
+        unsigned long long r = 0;
+        CRT_HIP(hipMemcpy(&r, sc->ray_counter, sizeof(r), hipMemcpyDeviceToHost));
+        *rays_out = r;
+    }
+    return CRT_OK;
+}
+
+int crt_render_range(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, float* seconds_out, uint64_t* rays_out) {
+    int rc = crt_render_launch(sc, buf, first_sample, samples, 0);
+    if (rc != CRT_OK) return rc;
+    float ms = 0.0f;
+    rc = crt_render_finish(sc, &ms, rays_out);
+    if (seconds_out) *seconds_out = ms * 1e-3f;
+    return rc;
+}
+
+int crt_render(crt_scene* sc, crt_buffers* buf, int samples, int samples_done, float* seconds_out, uint64_t* rays_out) {
+    crt::clear_error();
+    if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, "crt_render: null argument");
+    if (samples_done < 0) return crt::set_error(CRT_ERR_INVALID, "crt_render: samples_done must be >= 0");
+    if (samples < 0) samples = sc->render.samples_per_pixel;                       // render.cuh:120-124
+    else samples = std::min(samples, sc->render.samples_per_pixel);
+    if (samples == 0) {
+        if (seconds_out) *seconds_out = 0.0f;
+        if (rays_out) *rays_out = 0;
+        return CRT_OK;
+    }
+    int rc = crt_render_launch(sc, buf, samples_done, samples, samples_done);
+    if (rc != CRT_OK) return rc;
+    float ms = 0.0f;
+    rc = crt_render_finish(sc, &ms, rays_out);
+    if (seconds_out) *seconds_out = ms * 1e-3f;
+    return rc;
+}
+
+int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t, float* u, float* v, int32_t* front_face) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_trace_primary: null scene");
+    if (sample < 1) return crt::set_error(CRT_ERR_INVALID, "crt_trace_primary: sample numbers start at 1");
+    CRT_HIP(hipSetDevice(sc->device));
+    const size_t n = (size_t)sc->dev.width * sc->dev.height;
+    void* mem = nullptr;
+    CRT_HIP(hipMalloc(&mem, n * 20));
+    PrimaryArgs A;
+    A.sc = sc->dev;
+    A.sample = sample;
+    A.obj = static_cast<int32_t*>(mem);
+    A.t = reinterpret_cast<float*>(A.obj + n);
+    A.u = A.t + n;
+    A.v = A.u + n;
+    A.front = reinterpret_cast<int32_t*>(A.v + n);
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    switch (sc->stack_entries) {
+    case 8: hipLaunchKernelGGL((trace_primary_kernel<8>), grid, dim3(kBlock), 0, sc->stream, A); break;
+    case 16: hipLaunchKernelGGL((trace_primary_kernel<16>), grid, dim3(kBlock), 0, sc->stream, A); break;
+    case 32: hipLaunchKernelGGL((trace_primary_kernel<32>), grid, dim3(kBlock), 0, sc->stream, A); break;
+    default: hipLaunchKernelGGL((trace_primary_kernel<64>), grid, dim3(kBlock), 0, sc->stream, A); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);
+    if (e == hipSuccess && object_index) e = hipMemcpy(object_index, A.obj, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && t) e = hipMemcpy(t, A.t, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && u) e = hipMemcpy(u, A.u, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && v) e = hipMemcpy(v, A.v, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && front_face) e = hipMemcpy(front_face, A.front, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(mem);
+    if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_trace_primary: ") + hipGetErrorString(e));
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+/*
+ * crt.h -- C ABI of the MI355X path-tracing core.
+ *
+ * This library replaces ONE path of JasperJeuken/CudaRayTracer: everything behind
+ *     float render(std::unique_ptr<scene>&, std::unique_ptr<buffer>&, int tx, int ty,
+ *                  int samples, int samples_done)                       (src/render.cuh:167)
+ * i.e. render_kernel (render.cuh:108), get_ray_info (render.cuh:36) and every device
+ * function they call, plus the two hand-over structures either side of it:
+ * the scene that the kernel reads (device_scene, src/scene.cuh:26-37) and the six
+ * pass arrays it writes (buffer, src/buffer.cuh:321-334).
+ *
+ * Conventions
+ *   - every function returns CRT_OK (0) or a negative crt_status; the text of the last
+ *     error on the calling thread is returned by crt_last_error().  Nothing throws or
+ *     aborts across this boundary (the reference exits the process, utility.cuh:176-184).
+ *   - all pointers in the *_desc structures are caller-owned HOST memory that is copied
+ *     at crt_scene_create() time; the caller may free it afterwards.
+ *   - plain C types only.  float triples are float[3] in x,y,z order.
+ *   - one crt_render() may be in flight per scene at a time; it blocks until the device
+ *     has finished, like render.cuh:177.
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum crt_status {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = -1,   /* bad argument / inconsistent description      */
+    CRT_ERR_DEVICE = -2,    /* HIP runtime error, no device                 */
+    CRT_ERR_PARSE = -3,     /* scene file / OBJ file error                  */
+    CRT_ERR_IO = -4,        /* file could not be read or written            */
+    CRT_ERR_UNSUPPORTED = -5
+} crt_status;
+
+/* enum values follow the reference's declaration order */
+enum { CRT_OBJ_BVH = 0, CRT_OBJ_SPHERE = 1, CRT_OBJ_TRI = 2 };              /* hittable.cuh:16-20 */
+enum { CRT_MAT_LAMBERTIAN = 0, CRT_MAT_METAL = 1, CRT_MAT_DIELECTRIC = 2,
+       CRT_MAT_DIFFUSE_LIGHT = 3 };                                          /* material.cuh:14-20 */
+enum { CRT_TEX_SOLID_COLOR = 0, CRT_TEX_CHECKER = 1, CRT_TEX_IMAGE = 2 };    /* texture.cuh:20-24  */
+enum { CRT_CAM_PERSPECTIVE = 0, CRT_CAM_ORTHOGRAPHIC = 1 };                  /* camera.cuh:11-15   */
+
+/* One scene object in object-index order: the fields of `hittable` (hittable.cuh:27-37)
+ * followed by the `tri` (hittable.cuh:249-260) or `sphere` (hittable.cuh:136-137) payload. */
+typedef struct crt_object {
+    int32_t type;             /* CRT_OBJ_SPHERE | CRT_OBJ_TRI                              */
+    int32_t mat_idx;
+    int32_t normal_idx;       /* normal-map texture index or -1                            */
+    int32_t visible;          /* 0: dropped from the BVH (bvh.cuh:70-76)                   */
+    int32_t shade_smooth;     /* tri only                                                  */
+    float bbox_min[3];        /* padded bounding box as the reference stores it            */
+    float bbox_max[3];
+    float anchor[3];          /* anchor_point                                              */
+    float translation[3];
+    float rotation[9];        /* row-major m[r][c]                                         */
+    float rotation_inv[9];
+    /* tri: point, edge1, edge2.   sphere: center.origin, center.direction, {radius,0,0}   */
+    float p0[3], p1[3], p2[3];
+    float n0[3], n1[3], n2[3];    /* tri vertex normals (n0 = flat normal unless smooth)   */
+    float uv0[2], uv1[2], uv2[2]; /* tri                                                   */
+    float tangent[3], bitangent[3]; /* tri, precomputed (hittable.cuh:241-245)             */
+} crt_object;
+
+/* material.cuh:107-208 */
+typedef struct crt_material {
+    int32_t type;
+    int32_t tex_idx;          /* lambertian, diffuse_light                                 */
+    float albedo[3];          /* metal                                                     */
+    float fuzz;               /* metal                                                     */
+    float ior;                /* dielectric                                                */
+} crt_material;
+
+/* texture.cuh:68-124.  Image pixels are 8-bit, `channels` is 1 or 4 (RGB files are padded
+ * to RGBA by the loader, texture.cuh:150-151), rows top to bottom, tightly packed. */
+typedef struct crt_texture {
+    int32_t type;
+    float color[3];           /* solid_color                                               */
+    int32_t odd_idx, even_idx;/* checker                                                   */
+    float inv_scale;          /* checker                                                   */
+    int32_t width, height, channels; /* image                                              */
+    const uint8_t* pixels;    /* image, width*height*channels bytes                        */
+} crt_texture;
+
+/* Precomputed camera exactly as the host constructors leave it
+ * (perspective camera.cuh:121-151, orthographic camera.cuh:204-220). */
+typedef struct crt_camera {
+    int32_t type;
+    float center[3];          /* perspective only                                          */
+    float lower_left_corner[3]; /* centre of the UPPER-left pixel (camera.cuh:143-145)     */
+    float pixel_delta_u[3];
+    float pixel_delta_v[3];
+    float u[3], v[3], w[3];
+    float defocus_disk_u[3], defocus_disk_v[3];
+    float defocus_angle;      /* <= 0 : pinhole                                            */
+} crt_camera;
+
+/* camera.cuh:21-27 */
+typedef struct crt_render_info {
+    int32_t image_width, image_height, samples_per_pixel, max_bounces;
+    float gamma;
+} crt_render_info;
+
+/* Flat BVH4 in the reference's layout (bvh.cuh:17-23): 4 slots per node, slot = node*4+i,
+ * root = node 0; empty slot = (+inf,-inf,-1,-1) (bvh.cuh:236-239). */
+typedef struct crt_bvh4 {
+    int32_t slot_count;       /* 4 * node count (the reference calls this node_count)      */
+    const float* min_bounds;  /* [slot_count][3] */
+    const float* max_bounds;  /* [slot_count][3] */
+    const int32_t* children;  /* [slot_count]    */
+    const int32_t* object_index; /* [slot_count] */
+} crt_bvh4;
+
+/* What scene::scene() hands to the device (scene.cuh:26-37). */
+typedef struct crt_scene_desc {
+    int32_t object_count, material_count, texture_count, background_index;
+    const crt_object* objects;
+    const crt_material* materials;
+    const crt_texture* textures;
+    crt_bvh4 bvh;
+    crt_camera camera;
+    crt_render_info render;
+} crt_scene_desc;
+
+/* ------------------------------------------------------------------ host scene layer -- */
+
+typedef struct crt_host_scene crt_host_scene;   /* parsed scene, host memory only */
+
+/* Decodes an image file into 8-bit pixels (what stbi_load does at texture.cuh:143-147).
+ * Must return 0 and fill width/height/channels(1,3 or 4)/pixels (malloc'ed, the library
+ * frees it with free()) or non-zero on failure. */
+typedef int (*crt_image_loader_fn)(const char* filename, float hdr_gamma, float hdr_scale,
+                                   int desired_channels, int flip_y, int* width, int* height,
+                                   int* channels, uint8_t** pixels, void* user);
+
+/* Install the decoder used for `type: image` textures (NULL restores the built-in one). */
+int crt_set_image_loader(crt_image_loader_fn fn, void* user);
+
+/* load_scene() (scene.cuh:650-690): parse a YAML scene file, expand quads/boxes/models,
+ * apply translate/rotate, build the BVH4.  `base_dir` (may be NULL) is prepended to
+ * relative asset file names. */
+int crt_scene_load_yaml(const char* scene_file, const char* base_dir, crt_host_scene** out);
+/* Same from a YAML string already in memory. */
+int crt_scene_parse_yaml(const char* yaml_text, const char* base_dir, crt_host_scene** out);
+/* Override the render settings of a parsed scene (negative / zero = keep). Rebuilds the
+ * camera because pixel deltas depend on the image size. */
+int crt_host_scene_set_render(crt_host_scene* hs, int width, int height, int samples, int max_bounces);
+const crt_scene_desc* crt_host_scene_desc(const crt_host_scene* hs);
+void crt_host_scene_destroy(crt_host_scene* hs);
+
+/* create_bvh4() (bvh.cuh:299-310) on its own: n objects given by padded boxes and
+ * visibility flags.  Returns the slot count (4*nodes) or a negative status; call with
+ * NULL outputs to size the arrays (capacity is in slots). */
+int crt_bvh4_build(int n, const float* bbox_min, const float* bbox_max, const int32_t* visible,
+                   int capacity_slots, float* min_bounds, float* max_bounds,
+                   int32_t* children, int32_t* object_index);
+
+/* -------------------------------------------------------------------- device layer ---- */
+
+typedef struct crt_scene crt_scene;       /* scene resident in HBM of one GPU */
+typedef struct crt_buffers crt_buffers;   /* the six pass arrays in HBM       */
+
+int crt_device_count(int* count);
+/* Select the GPU the calling process renders on (one process per GPU). */
+int crt_set_device(int device);
+
+/* scene::scene() upload (scene.cuh:61-89): validates the description, repacks it into
+ * the device layout and copies it to HBM. */
+int crt_scene_create(const crt_scene_desc* desc, crt_scene** out);
+void crt_scene_destroy(crt_scene* sc);
+
+/* create_buffer() (buffer.cuh:344-380).  The six arrays are laid out like the reference:
+ * color, albedo, emission, normal = float[W*H][3]; depth, opacity = float[W*H];
+ * pixel_index = j*W + i, row 0 = top (render.cuh:113).
+ * crt_buffers_create allocates them; crt_buffers_wrap uses ONE caller-provided device
+ * allocation of 14*W*H floats holding the arrays back to back in the order above
+ * (so that a caller can hand the same memory to a collective). */
+int crt_buffers_create(int width, int height, crt_buffers** out);
+int crt_buffers_wrap(int width, int height, void* device_ptr_14wh_floats, crt_buffers** out);
+void crt_buffers_destroy(crt_buffers* buf);
+/* Copy passes to host arrays (any pointer may be NULL to skip that pass). */
+int crt_buffers_download(const crt_buffers* buf, float* color, float* albedo, float* emission,
+                         float* normal, float* depth, float* opacity);
+/* Copy host arrays into the device passes (to resume a progressive render). */
+int crt_buffers_upload(crt_buffers* buf, const float* color, const float* albedo,
+                       const float* emission, const float* normal, const float* depth,
+                       const float* opacity);
+
+/* render() (render.cuh:167-181).
+ *   samples < 0  -> samples_per_pixel; else min(samples, samples_per_pixel) (render.cuh:120-124)
+ *   sample numbers samples_done+1 .. samples_done+samples are folded into the running mean
+ *   held in `buf`; if samples_done == 0 the buffers are overwritten (render.cuh:128-152).
+ *   seconds_out (may be NULL): device time of the launch(es), like the clock() pair at
+ *   render.cuh:173-180.   rays_out (may be NULL): closest-hit queries traced = calls of
+ *   bvh4_hit at render.cuh:47.
+ * The random numbers of a path depend only on (pixel, sample number), so splitting a
+ * render into several calls, or over several GPUs, gives the same image. */
+int crt_render(crt_scene* sc, crt_buffers* buf, int samples, int samples_done,
+               float* seconds_out, uint64_t* rays_out);
+
+/* Multi-GPU form: render sample numbers first_sample+1 .. first_sample+samples and leave
+ * their MEAN in `buf` (overwriting it), without the samples_per_pixel clamp.  Ranks then
+ * combine means weighted by their sample counts. */
+int crt_render_range(crt_scene* sc, crt_buffers* buf, int first_sample, int samples,
+                     float* seconds_out, uint64_t* rays_out);
+
+/* Asynchronous pieces of crt_render_range for callers that time with their own events:
+ * launch on the scene's stream without waiting, then finish (sync + read ray counter).
+ * crt_scene_stream returns the hipStream_t as void*. */
+int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done);
+int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out);
+void* crt_scene_stream(crt_scene* sc);
+
+/* Kernel selection: 0 = fused persistent kernel (default), 1 = wavefront pipeline with
+ * per-bounce queue compaction.  Both produce the same image. */
+int crt_scene_set_mode(crt_scene* sc, int mode);
+
+/* Primary-ray probe used by the parity tests: for every pixel trace the camera ray of
+ * sample number `sample` (1-based, as in render.cuh:128) and return the closest hit of
+ * bounce 0: object index (-1 = miss), ray parameter t, surface u, v, front_face.
+ * Host output arrays of W*H entries each (any may be NULL). */
+int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t, float* u,
+                      float* v, int32_t* front_face);
+
+/* save_passes() (buffer.cuh:165-195): normalise the passes to 8 bit exactly like
+ * normalize_* (buffer.cuh:202-318) from HOST float arrays.  `out` = W*H*3 bytes.
+ * pass: 0 color 1 albedo 2 emission 3 normal 4 depth 5 opacity. */
+int crt_normalize_pass(int pass, int width, int height, float gamma, const float* data, uint8_t* out);
+/* write_image() (image.cuh:100-118) for fmt "png" | "bmp" | "tga" | "hdr" | "ppm". */
+int crt_write_image(const char* filename, const char* fmt, int width, int height, const uint8_t* rgb);
+
+const char* crt_last_error(void);
+const char* crt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

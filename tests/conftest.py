@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def crt():
+    import cudaraytracer_amd
+    return cudaraytracer_amd
+
+
+def scene_path(name):
+    return os.path.join(ROOT, "scenes", name)
