@@ -94,6 +94,7 @@ SIGNATURES = {
     "crt_render_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "crt_render_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_scene_stream": (C.c_void_p, [C.c_void_p]),
+    "crt_render_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crt_scene_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "crt_trace_primary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "crt_normalize_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

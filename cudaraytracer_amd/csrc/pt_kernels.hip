@@ -267,7 +267,8 @@ using namespace crt;
 struct crt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
+    float last_trace_ms = 0.0f, last_resolve_ms = 0.0f;
     void* blob = nullptr;            // nodes | prims | shade | xforms | mats | texs | images
     std::vector<void*> image_mem;
     DevScene dev = {};
@@ -395,6 +396,7 @@ void free_scene(crt_scene* sc) {
     if (sc->partial) (void)hipFree(sc->partial);
     if (sc->ray_counter) (void)hipFree(sc->ray_counter);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
+    if (sc->ev_mid) (void)hipEventDestroy(sc->ev_mid);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
@@ -526,6 +528,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     } while (0)
     CRT_HIP_OR_FREE(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
     CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_start));
+    CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_mid));
     CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_stop));
     for (size_t k = 0; k < images.size(); k++) {
         void* mem = nullptr;
@@ -698,6 +701,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     default: rc = launch_fused<64>(sc, A, grid); break;
     }
     if (rc != CRT_OK) return rc;
+    CRT_HIP(hipEventRecord(sc->ev_mid, sc->stream));
     ResolveArgs R;
     R.partial = sc->partial;
     R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
@@ -725,11 +729,21 @@ int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {
         CRT_HIP(hipEventElapsedTime(&ms, sc->ev_start, sc->ev_stop));
         *kernel_ms_out = ms;
     }
+    CRT_HIP(hipEventElapsedTime(&sc->last_trace_ms, sc->ev_start, sc->ev_mid));
+    CRT_HIP(hipEventElapsedTime(&sc->last_resolve_ms, sc->ev_mid, sc->ev_stop));
     if (rays_out) {
         unsigned long long r = 0;
         CRT_HIP(hipMemcpy(&r, sc->ray_counter, sizeof(r), hipMemcpyDeviceToHost));
         *rays_out = r;
     }
+    return CRT_OK;
+}
+
+int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_timings: null scene");
+    if (trace_ms) *trace_ms = sc->last_trace_ms;
+    if (resolve_ms) *resolve_ms = sc->last_resolve_ms;
     return CRT_OK;
 }
 

@@ -214,6 +214,9 @@ int crt_render_range(crt_scene* sc, crt_buffers* buf, int first_sample, int samp
 int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done);
 int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out);
 void* crt_scene_stream(crt_scene* sc);
+/* HIP-event durations of the last finished render on the scene's stream: the path-tracing
+ * kernel(s) and the pass-resolve kernel, in milliseconds. */
+int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms);
 
 /* Kernel selection: 0 = fused persistent kernel (default), 1 = wavefront pipeline with
  * per-bounce queue compaction.  Both produce the same image. */

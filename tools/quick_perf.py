@@ -1,0 +1,16 @@
+"""Quick device-time measurement of one scene (development helper)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cudaraytracer_amd as crt
+from cudaraytracer_amd import api
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name))
+buf = crt.create_buffer(sc)
+for r in range(reps):
+    t0 = time.time()
+    secs = crt.render(sc, buf)
+    wall = time.time() - t0
+    rays = api.last_ray_count
+    print(f"{name} rep{r}: device {secs*1e3:.2f} ms wall {wall*1e3:.2f} ms rays {rays} -> {rays/secs/1e6:.1f} Mrays/s", flush=True)
