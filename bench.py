@@ -59,13 +59,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="cornell_box.yaml")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=10, help="samples per pixel of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import cudaraytracer_amd as crt
+    from cudaraytracer_amd import multi_gpu
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,10 +92,10 @@ def main():
     dev = sc.get_device_scene()
 
     def step():
-        secs, rays = crt.render_range(sc, buf, rank * spp, spp)
+        first, count = multi_gpu.rank_sample_range(rank, world, spp)
+        secs, rays = crt.render_range(sc, buf, first, count)
         if world > 1:
-            passes.mul_(1.0 / world)           # equal sample counts per rank: mean of means
-            dist.all_reduce(passes)
+            multi_gpu.combine_means(passes, count, spp * world, dist)
             torch.cuda.current_stream().synchronize()
         tr, rs = C.c_float(0), C.c_float(0)
         lib.crt_render_timings(dev, C.byref(tr), C.byref(rs))
