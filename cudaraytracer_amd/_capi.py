@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_hip.so")
+# CRT_LIB selects another build of the same library (e.g. the -DCRT_PROFILE development build)
+LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt_hip.so")
 
 F3 = C.c_float * 3
 F2 = C.c_float * 2
@@ -95,6 +96,7 @@ SIGNATURES = {
     "crt_render_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_scene_stream": (C.c_void_p, [C.c_void_p]),
     "crt_render_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "crt_profile_counters": (C.c_int, [C.c_void_p, C.c_int]),
     "crt_scene_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "crt_trace_primary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "crt_normalize_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

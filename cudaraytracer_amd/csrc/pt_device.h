@@ -30,6 +30,25 @@
 
 namespace crt {
 
+// Profiling build (-DCRT_PROFILE): wave-level iteration counts and active-lane sums of the
+// kernel's loops, accumulated in a device array (slot 2k = times the wave executed site k,
+// slot 2k+1 = lanes active there).  Compiled out of the product build.
+#ifdef CRT_PROFILE
+__device__ unsigned long long g_prof[32];
+__device__ __forceinline__ void prof_tick(int site) {
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) {
+        atomicAdd(&g_prof[2 * site], 1ull);
+        atomicAdd(&g_prof[2 * site + 1], (unsigned long long)__builtin_popcountll(m));
+    }
+}
+#define CRT_PROF(site) prof_tick(site)
+#else
+#define CRT_PROF(site) ((void)0)
+#endif
+enum { kProfOuter = 0, kProfRegen = 1, kProfTrace = 2, kProfNode = 3, kProfPrim = 4, kProfShade = 5, kProfReject = 6,
+       kProfXform = 7, kProfPush = 8 };
+
 constexpr float kPi = 3.1415926535897932385f;
 constexpr int kNodeFields = 7;        // minx miny minz maxx maxy maxz code   (float4 / int4 each)
 constexpr int kNodeStrideGlobal = 8;  // float4 per node in HBM (one 128-byte line)
@@ -92,6 +111,7 @@ struct Rng {
 
 __device__ __forceinline__ V3 random_unit_vector(Rng& r) {            // vec3.cuh:204-212
     while (true) {
+        CRT_PROF(kProfReject);
         V3 p = r.range3(-1.0f, 1.0f);
         float lensq = length_squared(p);
         if (1e-30f < lensq && lensq <= 1.0f) return unit(p);
@@ -219,15 +239,29 @@ __device__ __forceinline__ bool prim_test(const Mem& S, int obj, const Ray& r, f
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
     int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
     V3 o = r.o, d = r.d;
-    if (xf >= 0) to_object_space(S.xform(xf), r.o, r.d, o, d);
+    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(S.xform(xf), r.o, r.d, o, d); }
     if (type == 2) return tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, tmax, t, bu, bv);
     bu = 0.0f; bv = 0.0f;
     return sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, t);
 }
 
-// Closest hit over the flat BVH4.  Visits the four slots of a node in storage order and
-// pops the most recently pushed child first, like bvh.cuh:387-419, so that candidates with
-// exactly equal t resolve to the same object as in the reference.
+// Closest hit over the flat BVH4.
+//
+// Order of evaluation per ray follows bvh.cuh:387-419: the four slots of a node in storage
+// order, a leaf slot's primitive tested before later slots are considered (so a later slot
+// sees the shrunken interval), internal children pushed in slot order and popped last-in
+// first-out.  Candidates with exactly equal t therefore resolve to the same object as in the
+// reference.  (In a node that mixes leaf and internal slots the internal children are pushed
+// on the interval at node entry, a superset of what the reference pushes; its own builder
+// never produces such nodes.)
+//
+// For the wave the work is split into two alternating phases ("while-while"):
+//   node phase  every lane that has no pending primitives descends (box tests, pushes, pop)
+//               until it reaches a node with leaf candidates or runs out of nodes;
+//   prim phase  every lane tests its pending candidates, one per round, in slot order.
+// Lanes reach leaves at different times; testing primitives the moment one lane finds them
+// would run the long intersection code for a handful of lanes (measured: 8 % of the lanes
+// active), while batching them keeps both phases mostly full.
 template <class Mem>
 __device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, float tmax, LaneStack stk) {
     // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
@@ -242,35 +276,106 @@ __device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, 
     Hit best;
     best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
     int sp = 0;
-    int node = 0;
+    int node = 0;                       // next node to visit, -1 when the stack ran empty
+    unsigned leaf_mask = 0;             // pending leaf slots of the last visited node
+    int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+    float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
     while (true) {
-        float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
-        float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
-        float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
-        float4 codef = S.node_field(node, 6);
-        const float nxs[4] = {bnx.x, bnx.y, bnx.z, bnx.w}, fxs[4] = {bfx.x, bfx.y, bfx.z, bfx.w};
-        const float nys[4] = {bny.x, bny.y, bny.z, bny.w}, fys[4] = {bfy.x, bfy.y, bfy.z, bfy.w};
-        const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
-        const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
+        while (node >= 0 && leaf_mask == 0) {                       // ---- node phase
+            CRT_PROF(kProfNode);
+            float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
+            float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
+            float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
+            float4 codef = S.node_field(node, 6);
+            const float nxs[4] = {bnx.x, bnx.y, bnx.z, bnx.w}, fxs[4] = {bfx.x, bfx.y, bfx.z, bfx.w};
+            const float nys[4] = {bny.x, bny.y, bny.z, bny.w}, fys[4] = {bfy.x, bfy.y, bfy.z, bfy.w};
+            const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
+            const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
+            float los[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
-            float lo = fmaxf(tmin, t0), hi = fminf(best.t, t1);
-            t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
-            lo = fmaxf(lo, t0); hi = fminf(hi, t1);
-            t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
-            lo = fmaxf(lo, t0); hi = fminf(hi, t1);
-            if (hi < lo) continue;
-            int code = codes[i];
-            if (code >= 0) {
-                float t, bu, bv;
-                if (prim_test(S, code, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = code; best.bu = bu; best.bv = bv; }
-            } else if (code < -1) {
-                stk.put(sp++, -code - 2);
+            for (int i = 0; i < 4; i++) {
+                float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
+                float lo = fmaxf(tmin, t0), hi = fminf(best.t, t1);
+                t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
+                lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+                t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
+                lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+                los[i] = lo;
+                if (!(hi < lo)) {
+                    if (codes[i] >= 0) leaf_mask |= 1u << i;
+                    else if (codes[i] < -1) stk.put(sp++, -codes[i] - 2);
+                }
             }
+            c0 = codes[0]; c1 = codes[1]; c2 = codes[2]; c3 = codes[3];
+            l0 = los[0]; l1 = los[1]; l2 = los[2]; l3 = los[3];
+            if (leaf_mask == 0) node = sp ? stk.get(--sp) : -1;
         }
-        if (sp == 0) break;
-        node = stk.get(--sp);
+        if (leaf_mask == 0) break;                                  // no node left and nothing pending
+        while (leaf_mask) {                                         // ---- prim phase
+            const int i = __builtin_ctz(leaf_mask);
+            leaf_mask &= leaf_mask - 1;
+            const int code = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3));
+            const float lo = i == 0 ? l0 : (i == 1 ? l1 : (i == 2 ? l2 : l3));
+            // an earlier slot of this node may have shrunk the interval below this box's entry:
+            // the reference's slab test (run after that hit) would reject the slot
+            if (best.t < lo) continue;
+            CRT_PROF(kProfPrim);
+            float t, bu, bv;
+            if (prim_test(S, code, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = code; best.bu = bu; best.bv = bv; }
+        }
+        node = sp ? stk.get(--sp) : -1;
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ flat traversal ------
+// Small scenes (at most 64 objects).  The reference's traversal never sorts children by
+// distance, so the order in which leaf slots are visited is a fixed depth-first order that does
+// not depend on the ray (bvh.cuh:387-419: slots 0..3 in order, pushed children popped last-in
+// first-out).  The host lays the leaf slots out in exactly that order ("entries").  A ray then
+//   1. runs the slab test against every entry's box in a loop that is UNIFORM across the wave:
+//      box data comes through scalar loads from the constant address space, there is no stack,
+//      no per-lane addressing and no divergence, and sets one bit per entry whose box it hits;
+//   2. tests its candidate primitives in entry order, one per round, with the shrinking interval.
+// This visits a superset of the boxes the tree walk visits (the inner boxes of a 36-triangle
+// tree reject almost nothing: 31 box tests per ray through the tree, 36 here) but removes all
+// traversal divergence, which costs a 64-wide wave far more than the few extra tests.
+// Result: same closest hit, same tie resolution (entry order = reference visiting order; the
+// slab test of step 1 uses the open interval [tmin, inf) and step 2 re-applies the interval test
+// exactly as the reference's primitive test does).
+typedef float NativeQuad __attribute__((ext_vector_type(4)));
+typedef const NativeQuad __attribute__((address_space(4))) * ConstQuadPtr;
+
+struct FlatBoxes {
+    ConstQuadPtr quads;   // [count][2]: {minx, maxx, miny, maxy}, {minz, maxz, 0, 0}
+    int count;
+};
+
+template <class Mem>
+__device__ __forceinline__ Hit traverse_flat(const Mem& S, const FlatBoxes& F, const Ray& r, float tmin, float tmax) {
+    const float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;     // aabb.cuh:140
+    const float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
+    const float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
+    unsigned long long cand = 0;
+    for (int e = 0; e < F.count; e++) {
+        const NativeQuad b0 = F.quads[2 * e], b1 = F.quads[2 * e + 1];
+        // For a non-empty box min <= max, so the reference's swap on a negative reciprocal
+        // (aabb.cuh:144-148) selects exactly fmin/fmax of the two plane distances.
+        const float ax = (b0.x - r.o.x) * ix, bx = (b0.y - r.o.x) * ix;
+        const float ay = (b0.z - r.o.y) * iy, by = (b0.w - r.o.y) * iy;
+        const float az = (b1.x - r.o.z) * iz, bz = (b1.y - r.o.z) * iz;
+        const float lo = fmaxf(fmaxf(fmaxf(tmin, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
+        const float hi = fminf(fminf(fminf(tmax, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
+        if (!(hi < lo)) cand |= 1ull << e;
+    }
+    Hit best;
+    best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
+    while (cand) {
+        CRT_PROF(kProfPrim);
+        const int e = __builtin_ctzll(cand);
+        cand &= cand - 1;
+        float t, bu, bv;
+        if (prim_test(S, e, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = e; best.bu = bu; best.bv = bv; }
     }
     return best;
 }

@@ -29,15 +29,26 @@
 namespace crt {
 
 constexpr int kBlock = 256;          // 4 waves; one 8x8 pixel tile per wave
+constexpr int kWaves = kBlock / 64;
 constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
+
+// How a kernel reaches the scene geometry
+enum : int {
+    kModeTreeGlobal = 0,   // BVH4 walk, node/primitive records read from HBM through L1/L2
+    kModeTreeLds = 1,      // BVH4 walk over a field-major copy of the scene in LDS
+    kModeFlat = 2          // <= 64 objects: wave-uniform box loop + per-lane candidate mask
+};
 
 struct RenderArgs {
     DevScene sc;
+    const float4* flat_boxes;        // [flat_count][2], entry = leaf slot in reference visiting order
+    const float4* flat_prims;        // [flat_count][3] primitive records in entry order
+    const int32_t* flat_obj;         // entry -> object index
+    int flat_count;
     float* partial;                  // [chunks][14][pix_padded]  chunk sums, tile-major pixels
     unsigned long long* ray_counter;
     int tiles_x, tiles_y, ntiles, pix_padded;
     int first_sample, samples, chunk_size;
-    int lds_scene_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap(int block, int nblocks) {
@@ -49,69 +60,71 @@ __device__ __forceinline__ int xcd_remap(int block, int nblocks) {
     return start + k;
 }
 
-template <bool LDS>
-struct MemOf;
-template <>
-struct MemOf<false> { using type = SceneGlobal; };
-template <>
-struct MemOf<true> { using type = SceneLds; };
-
-template <bool LDS>
-__device__ __forceinline__ typename MemOf<LDS>::type make_mem(const DevScene& sc, float4* lds_scene) {
-    if constexpr (LDS) {
-        // cooperative copy HBM -> LDS, transposing nodes and primitives to field-major
-        const int nn = sc.node_count, no = sc.object_count;
-        float4* ln = lds_scene;
-        float4* lp = ln + kNodeFields * nn;
-        float* lx = reinterpret_cast<float*>(lp + kPrimQuads * no);
-        for (int i = threadIdx.x; i < nn * kNodeFields; i += kBlock) {
-            int node = i / kNodeFields, f = i - node * kNodeFields;
-            ln[f * nn + node] = sc.nodes[node * kNodeStrideGlobal + f];
-        }
-        for (int i = threadIdx.x; i < no * kPrimQuads; i += kBlock) {
-            int obj = i / kPrimQuads, q = i - obj * kPrimQuads;
-            lp[q * no + obj] = sc.prims[i];
-        }
-        for (int i = threadIdx.x; i < sc.xform_count * kXformFloats; i += kBlock) lx[i] = sc.xforms[i];
-        __syncthreads();
-        SceneLds m;
-        m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no;
-        return m;
-    } else {
-        SceneGlobal m;
-        m.nodes = sc.nodes; m.prims = sc.prims; m.xforms = sc.xforms;
-        return m;
+// Cooperative copy of the traversal data HBM -> LDS (field-major, see SceneLds).
+__device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int nn, const float4* prims, int no,
+                                                       const float* xforms, int nx, float4* lds) {
+    float4* ln = lds;
+    float4* lp = ln + kNodeFields * nn;
+    float* lx = reinterpret_cast<float*>(lp + kPrimQuads * no);
+    for (int i = threadIdx.x; i < nn * kNodeFields; i += kBlock) {
+        int node = i / kNodeFields, f = i - node * kNodeFields;
+        ln[f * nn + node] = nodes[node * kNodeStrideGlobal + f];
     }
+    for (int i = threadIdx.x; i < no * kPrimQuads; i += kBlock) {
+        int obj = i / kPrimQuads, q = i - obj * kPrimQuads;
+        lp[q * no + obj] = prims[i];
+    }
+    for (int i = threadIdx.x; i < nx * kXformFloats; i += kBlock) lx[i] = xforms[i];
+    SceneLds m;
+    m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no;
+    return m;
 }
 
-template <int STACK, bool LDS>
+// LDS carve-up of a block: [pass sums: waves x 14 x 64 floats][stacks: STACK x 256 ints][scene copy]
+constexpr int kAccFloatsPerWave = kPasses * 64;
+
+template <int MODE, int STACK>
 __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
     extern __shared__ float4 smem[];
-    int* stack_mem = reinterpret_cast<int*>(smem);
-    float4* lds_scene = smem + (STACK * kBlock) / 4;
+    float* acc_all = reinterpret_cast<float*>(smem);
+    int* stack_mem = reinterpret_cast<int*>(acc_all + kWaves * kAccFloatsPerWave);
+    float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
     const DevScene& sc = A.sc;
-    auto S = make_mem<LDS>(sc, lds_scene);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x) * (kBlock / 64) + wave;
+    float* acc = acc_all + wave * kAccFloatsPerWave;              // [14][64] sums of this wave's tile
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) acc[k * 64 + lane] = 0.0f;
+
+    SceneGlobal SG;
+    SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms;
+    SceneLds SL = {};
+    if constexpr (MODE == kModeTreeLds) SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene);
+    if constexpr (MODE == kModeFlat) SL = stage_scene_in_lds(sc.nodes, 0, A.flat_prims, A.flat_count, sc.xforms, sc.xform_count, lds_scene);
+    __syncthreads();
+    FlatBoxes FB;
+    FB.quads = (ConstQuadPtr)A.flat_boxes;
+    FB.count = A.flat_count;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
     if (tile >= A.ntiles) return;
     const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
-    const int pi = tx * 8 + (lane & 7), pj = ty * 8 + (lane >> 3);
-    const bool valid = pi < sc.width && pj < sc.height;
-    const int pixel_index = pj * sc.width + pi;
     LaneStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.stride = kBlock;
 
+    // Work pool of the wave: items (sample, pixel of the tile), sample-major.  A lane whose path
+    // ended takes the next item, whichever pixel it belongs to, so the wave stays full until the
+    // pool is empty; finished paths add their results to the tile's sums in LDS.
     const int chunk = blockIdx.y;
-    int s = A.first_sample + chunk * A.chunk_size;                  // samples already started
-    const int s_end = min(s + A.chunk_size, A.first_sample + A.samples);
+    const int s0 = A.first_sample + chunk * A.chunk_size;
+    const int s1 = min(s0 + A.chunk_size, A.first_sample + A.samples);
+    const int total_items = (s1 - s0) * 64;
+    int next_item = 0;                                            // wave-uniform
 
-    V3 sum_col = v3(0, 0, 0), sum_alb = v3(0, 0, 0), sum_emi = v3(0, 0, 0), sum_nrm = v3(0, 0, 0);
-    float sum_depth = 0.0f, sum_opacity = 0.0f;
     unsigned int rays = 0;
-
     bool alive = false;
+    int pix = lane;                                               // pixel of the tile this lane's path belongs to
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
@@ -120,29 +133,52 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
     rng.state = 0; rng.draws = 0;
 
     while (true) {
-        if (!alive && valid && s < s_end) {                          // regenerate: next sample of this pixel
-            s++;
-            rng.init(pixel_index, s);
-            ray = camera_ray(sc.cam, pi, pj, rng);
-            throughput = v3(1, 1, 1);
-            pend_albedo = v3(0, 0, 0);
-            bounces = 0;
-            alive = sc.max_bounces > 0;                              // render.cuh:44 with max_bounces == 0
+        CRT_PROF(kProfOuter);
+        if (next_item < total_items) {                            // wave-uniform
+            const unsigned long long free_mask = __ballot(!alive);
+            if (!alive) {
+                CRT_PROF(kProfRegen);
+                const int item = next_item + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
+                if (item < total_items) {
+                    pix = item & 63;
+                    const int sample = s0 + (item >> 6) + 1;      // sample numbers are 1-based (render.cuh:128)
+                    const int pi = tx * 8 + (pix & 7), pj = ty * 8 + (pix >> 3);
+                    if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
+                        rng.init(pj * sc.width + pi, sample);
+                        ray = camera_ray(sc.cam, pi, pj, rng);
+                        throughput = v3(1, 1, 1);
+                        pend_albedo = v3(0, 0, 0);
+                        bounces = 0;
+                        alive = true;
+                    }
+                }
+            }
+            next_item += __builtin_popcountll(free_mask);
         }
-        if (!__any(alive)) break;
+        if (!__any(alive)) {
+            if (next_item >= total_items) break;
+            continue;
+        }
         if (alive) {
             rays++;
-            Hit h = traverse(S, ray, 0.001f, INFINITY, stk);        // render.cuh:47
+            CRT_PROF(kProfTrace);
+            Hit h;
+            if constexpr (MODE == kModeFlat) h = traverse_flat(SL, FB, ray, 0.001f, INFINITY);
+            else if constexpr (MODE == kModeTreeLds) h = traverse(SL, ray, 0.001f, INFINITY, stk);
+            else h = traverse(SG, ray, 0.001f, INFINITY, stk);    // render.cuh:47
             if (h.obj >= 0) {
+                CRT_PROF(kProfShade);
+                if constexpr (MODE == kModeFlat) h.obj = A.flat_obj[h.obj];
                 Surface sf = make_surface(sc, ray, h);
                 V3 attenuation;
                 Ray next;
                 if (scatter(sc, ray, sf, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         pend_albedo = attenuation;
-                        sum_nrm = sum_nrm + unit(sf.normal);
-                        sum_depth += h.t * length(ray.d);
-                        sum_opacity += 1.0f;
+                        V3 n = unit(sf.normal);
+                        atomicAdd(&acc[9 * 64 + pix], n.x); atomicAdd(&acc[10 * 64 + pix], n.y); atomicAdd(&acc[11 * 64 + pix], n.z);
+                        atomicAdd(&acc[12 * 64 + pix], h.t * length(ray.d));
+                        atomicAdd(&acc[13 * 64 + pix], 1.0f);
                     }
                     throughput = throughput * attenuation;
                     ray = next;
@@ -150,39 +186,39 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
                     if (bounces >= sc.max_bounces) alive = false;   // exhausted: col = albedo = 0 (render.cuh:96-97)
                 } else {                                             // render.cuh:64-74
                     V3 emitted = emit(sc, sf);
-                    sum_col = sum_col + throughput * emitted;
+                    V3 c = throughput * emitted;
+                    atomicAdd(&acc[0 * 64 + pix], c.x); atomicAdd(&acc[1 * 64 + pix], c.y); atomicAdd(&acc[2 * 64 + pix], c.z);
+                    V3 alb = pend_albedo;
                     if (bounces == 0) {
-                        sum_alb = sum_alb + emitted;
-                        sum_emi = sum_emi + emitted;
-                        sum_nrm = sum_nrm + unit(sf.normal);
-                        sum_depth += h.t * length(ray.d);
-                        sum_opacity += 1.0f;
-                    } else {
-                        sum_alb = sum_alb + pend_albedo;
+                        alb = emitted;
+                        V3 n = unit(sf.normal);
+                        atomicAdd(&acc[6 * 64 + pix], emitted.x); atomicAdd(&acc[7 * 64 + pix], emitted.y); atomicAdd(&acc[8 * 64 + pix], emitted.z);
+                        atomicAdd(&acc[9 * 64 + pix], n.x); atomicAdd(&acc[10 * 64 + pix], n.y); atomicAdd(&acc[11 * 64 + pix], n.z);
+                        atomicAdd(&acc[12 * 64 + pix], h.t * length(ray.d));
+                        atomicAdd(&acc[13 * 64 + pix], 1.0f);
                     }
+                    atomicAdd(&acc[3 * 64 + pix], alb.x); atomicAdd(&acc[4 * 64 + pix], alb.y); atomicAdd(&acc[5 * 64 + pix], alb.z);
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment(sc, ray.d);
-                sum_col = sum_col + c;
+                atomicAdd(&acc[0 * 64 + pix], c.x); atomicAdd(&acc[1 * 64 + pix], c.y); atomicAdd(&acc[2 * 64 + pix], c.z);
+                V3 alb = pend_albedo;
                 if (bounces == 0) {
-                    sum_alb = sum_alb + c;
-                    sum_depth += __builtin_nanf("");
-                } else {
-                    sum_alb = sum_alb + pend_albedo;
+                    alb = c;
+                    atomicAdd(&acc[12 * 64 + pix], __builtin_nanf(""));
                 }
+                atomicAdd(&acc[3 * 64 + pix], alb.x); atomicAdd(&acc[4 * 64 + pix], alb.y); atomicAdd(&acc[5 * 64 + pix], alb.z);
                 alive = false;
             }
         }
     }
 
+    // tile sums -> HBM (lane = pixel of the tile); the wave's own LDS adds are complete here
     float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * 64 + lane;
     const size_t ps = A.pix_padded;
-    out[0 * ps] = sum_col.x; out[1 * ps] = sum_col.y; out[2 * ps] = sum_col.z;
-    out[3 * ps] = sum_alb.x; out[4 * ps] = sum_alb.y; out[5 * ps] = sum_alb.z;
-    out[6 * ps] = sum_emi.x; out[7 * ps] = sum_emi.y; out[8 * ps] = sum_emi.z;
-    out[9 * ps] = sum_nrm.x; out[10 * ps] = sum_nrm.y; out[11 * ps] = sum_nrm.z;
-    out[12 * ps] = sum_depth; out[13 * ps] = sum_opacity;
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) out[k * ps] = acc[k * 64 + lane];
 
     // one ray-count atomic per wave
     unsigned int total = rays;
@@ -229,27 +265,45 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
 // Bounce-0 closest hit per pixel for the parity tables.
 struct PrimaryArgs {
     DevScene sc;
+    const float4* flat_boxes;
+    const float4* flat_prims;
+    const int32_t* flat_obj;
+    int flat_count;
     int sample;
     int32_t* obj;
     float *t, *u, *v;
     int32_t* front;
 };
-template <int STACK>
+template <int MODE, int STACK>
 __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
-    __shared__ int stack_mem[STACK * kBlock];
+    extern __shared__ float4 smem[];
+    int* stack_mem = reinterpret_cast<int*>(smem);
+    float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
     const DevScene& sc = A.sc;
+    SceneLds SL = {};
+    if constexpr (MODE == kModeFlat) SL = stage_scene_in_lds(sc.nodes, 0, A.flat_prims, A.flat_count, sc.xforms, sc.xform_count, lds_scene);
+    __syncthreads();
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= sc.width * sc.height) return;
     const int pi = idx % sc.width, pj = idx / sc.width;
-    SceneGlobal S;
-    S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms;
-    LaneStack stk;
-    stk.base = stack_mem + threadIdx.x;
-    stk.stride = kBlock;
     Rng rng;
     rng.init(idx, A.sample);
     Ray ray = camera_ray(sc.cam, pi, pj, rng);
-    Hit h = traverse(S, ray, 0.001f, INFINITY, stk);
+    Hit h;
+    if constexpr (MODE == kModeFlat) {
+        FlatBoxes FB;
+        FB.quads = (ConstQuadPtr)A.flat_boxes;
+        FB.count = A.flat_count;
+        h = traverse_flat(SL, FB, ray, 0.001f, INFINITY);
+        if (h.obj >= 0) h.obj = A.flat_obj[h.obj];
+    } else {
+        SceneGlobal S;
+        S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms;
+        LaneStack stk;
+        stk.base = stack_mem + threadIdx.x;
+        stk.stride = kBlock;
+        h = traverse(S, ray, 0.001f, INFINITY, stk);
+    }
     A.obj[idx] = h.obj;
     if (h.obj >= 0) {
         Surface sf = make_surface(sc, ray, h);
@@ -274,9 +328,14 @@ struct crt_scene {
     DevScene dev = {};
     crt_render_info render = {};
     int stack_entries = 8;
-    bool lds_scene = false;
-    int lds_scene_bytes = 0;
-    int mode = 0;
+    int lds_scene_bytes = 0;         // field-major copy of nodes + prims + xforms
+    int lds_flat_bytes = 0;          // flat mode: prims in entry order + xforms
+    bool can_lds = false, can_flat = false;
+    const float4* flat_boxes = nullptr;
+    const float4* flat_prims = nullptr;
+    const int32_t* flat_obj = nullptr;
+    int flat_count = 0;
+    int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
     float* partial = nullptr;
     size_t partial_bytes = 0;
     unsigned long long* ray_counter = nullptr;
@@ -402,16 +461,58 @@ void free_scene(crt_scene* sc) {
     delete sc;
 }
 
+int kernel_mode(const crt_scene* sc) {
+    switch (sc->mode) {
+    case 1: return kModeTreeGlobal;
+    case 2: return sc->can_lds ? kModeTreeLds : kModeTreeGlobal;
+    case 3: return sc->can_flat ? kModeFlat : (sc->can_lds ? kModeTreeLds : kModeTreeGlobal);
+    default: return sc->can_flat ? kModeFlat : (sc->can_lds ? kModeTreeLds : kModeTreeGlobal);
+    }
+}
+
 template <int STACK>
-int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
-    size_t lds = (size_t)STACK * kBlock * sizeof(int) + (sc->lds_scene ? (size_t)sc->lds_scene_bytes : 0);
-    if (sc->lds_scene) {
-        hipLaunchKernelGGL((render_fused<STACK, true>), grid, dim3(kBlock), lds, sc->stream, A);
+int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
+    size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)STACK * kBlock * sizeof(int);
+    if (mode == kModeTreeLds) {
+        lds += (size_t)sc->lds_scene_bytes;
+        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK>), grid, dim3(kBlock), lds, sc->stream, A);
     } else {
-        hipLaunchKernelGGL((render_fused<STACK, false>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK>), grid, dim3(kBlock), lds, sc->stream, A);
     }
     CRT_HIP(hipGetLastError());
     return CRT_OK;
+}
+
+int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
+    const int mode = kernel_mode(sc);
+    if (mode == kModeFlat) {
+        size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)sc->lds_flat_bytes;
+        hipLaunchKernelGGL((render_fused<kModeFlat, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+        CRT_HIP(hipGetLastError());
+        return CRT_OK;
+    }
+    switch (sc->stack_entries) {
+    case 8: return launch_tree<8>(sc, A, grid, mode);
+    case 16: return launch_tree<16>(sc, A, grid, mode);
+    case 32: return launch_tree<32>(sc, A, grid, mode);
+    default: return launch_tree<64>(sc, A, grid, mode);
+    }
+}
+
+// Leaf slots in the order the reference's traversal visits them when every box is hit
+// (bvh.cuh:387-419): slots 0..3 of a node in order, pushed children popped last-in first-out.
+void reference_visit_order(const crt_bvh4& b, std::vector<int>& leaf_slots) {
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        int node = stack.back();
+        stack.pop_back();
+        for (int i = 0; i < 4; i++) {
+            int s = node * 4 + i;
+            if (b.object_index[s] >= 0) leaf_slots.push_back(s);
+            if (b.children[s] >= 0) stack.push_back(b.children[s]);
+        }
+    }
 }
 
 }  // namespace
@@ -519,6 +620,24 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         }
     }
 
+    // flat list for small scenes
+    std::vector<int> leaf_slots;
+    reference_visit_order(d->bvh, leaf_slots);
+    const bool can_flat = !leaf_slots.empty() && leaf_slots.size() <= 64;
+    std::vector<float> flat_box_rec, flat_prim_rec;
+    std::vector<int32_t> flat_obj_rec;
+    if (can_flat) {
+        for (int s : leaf_slots) {
+            const float* mn = d->bvh.min_bounds + 3 * s;
+            const float* mx = d->bvh.max_bounds + 3 * s;
+            const float rec[8] = {mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], 0.0f, 0.0f};
+            flat_box_rec.insert(flat_box_rec.end(), rec, rec + 8);
+            int o = d->bvh.object_index[s];
+            flat_obj_rec.push_back(o);
+            flat_prim_rec.insert(flat_prim_rec.end(), &prim_rec[(size_t)o * kPrimQuads * 4], &prim_rec[(size_t)(o + 1) * kPrimQuads * 4]);
+        }
+    }
+
     crt_scene* sc = new crt_scene();
     if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; return crt::set_error(CRT_ERR_DEVICE, "crt_scene_create: no HIP device"); }
 #define CRT_HIP_OR_FREE(call)                                                                                          \
@@ -547,6 +666,9 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     size_t off_mats = blob.add(mat_rec.data(), mat_rec.size() * 4);
     size_t off_texs = blob.add(tex_rec.data(), tex_rec.size() * 4);
     size_t off_img = blob.add(images.data(), images.size() * sizeof(DevImage));
+    size_t off_fbox = blob.add(flat_box_rec.data(), flat_box_rec.size() * 4);
+    size_t off_fprim = blob.add(flat_prim_rec.data(), flat_prim_rec.size() * 4);
+    size_t off_fobj = blob.add(flat_obj_rec.data(), flat_obj_rec.size() * 4);
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
@@ -579,9 +701,15 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     sc->render = d->render;
     sc->stack_entries = stack_entries;
     sc->lds_scene_bytes = (int)(((size_t)nodes * kNodeFields + (size_t)d->object_count * kPrimQuads) * 16 + xforms.size() * 4);
-    // keep a block (stack + scene copy) under 40 KB so that four blocks still fit a CU
-    sc->lds_scene = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 <= 40 * 1024;
-    if (const char* e = std::getenv("CRT_LDS_SCENE")) sc->lds_scene = sc->lds_scene && std::atoi(e) != 0;
+    // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
+    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + kWaves * kAccFloatsPerWave * 4 <= 40 * 1024;
+    sc->can_flat = can_flat;
+    sc->flat_count = can_flat ? (int)leaf_slots.size() : 0;
+    sc->lds_flat_bytes = (int)((size_t)sc->flat_count * kPrimQuads * 16 + xforms.size() * 4);
+    sc->flat_boxes = reinterpret_cast<const float4*>(base + off_fbox);
+    sc->flat_prims = reinterpret_cast<const float4*>(base + off_fprim);
+    sc->flat_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
+    if (const char* e = std::getenv("CRT_MODE")) sc->mode = std::atoi(e);
     *out = sc;
     return CRT_OK;
 }
@@ -591,7 +719,7 @@ void crt_scene_destroy(crt_scene* sc) { free_scene(sc); }
 int crt_scene_set_mode(crt_scene* sc, int mode) {
     crt::clear_error();
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_set_mode: null scene");
-    if (mode != 0) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_set_mode: only mode 0 (fused) is available");
+    if (mode < 0 || mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_set_mode: mode must be 0..3");
     sc->mode = mode;
     return CRT_OK;
 }
@@ -679,7 +807,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     chunks = (samples + A.chunk_size - 1) / A.chunk_size;
     A.first_sample = first_sample;
     A.samples = samples;
-    A.lds_scene_bytes = sc->lds_scene_bytes;
+    A.flat_boxes = sc->flat_boxes; A.flat_prims = sc->flat_prims; A.flat_obj = sc->flat_obj; A.flat_count = sc->flat_count;
     size_t need = (size_t)chunks * kPasses * A.pix_padded * sizeof(float);
     if (need > sc->partial_bytes) {
         if (sc->partial) CRT_HIP(hipFree(sc->partial));
@@ -693,13 +821,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, sizeof(unsigned long long), sc->stream));
     dim3 grid((A.ntiles + (kBlock / 64) - 1) / (kBlock / 64), chunks);
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
-    int rc;
-    switch (sc->stack_entries) {
-    case 8: rc = launch_fused<8>(sc, A, grid); break;
-    case 16: rc = launch_fused<16>(sc, A, grid); break;
-    case 32: rc = launch_fused<32>(sc, A, grid); break;
-    default: rc = launch_fused<64>(sc, A, grid); break;
-    }
+    int rc = launch_fused(sc, A, grid);
     if (rc != CRT_OK) return rc;
     CRT_HIP(hipEventRecord(sc->ev_mid, sc->stream));
     ResolveArgs R;
@@ -747,6 +869,26 @@ int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms) {
     return CRT_OK;
 }
 
+int crt_profile_counters(uint64_t* out32, int reset) {
+    crt::clear_error();
+#ifdef CRT_PROFILE
+    unsigned long long host[32];
+    if (out32) {
+        CRT_HIP(hipDeviceSynchronize());
+        CRT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(crt::g_prof), sizeof(host)));
+        for (int i = 0; i < 32; i++) out32[i] = host[i];
+    }
+    if (reset) {
+        std::memset(host, 0, sizeof(host));
+        CRT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(crt::g_prof), host, sizeof(host)));
+    }
+    return CRT_OK;
+#else
+    (void)out32; (void)reset;
+    return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_profile_counters: this library was built without -DCRT_PROFILE");
+#endif
+}
+
 int crt_render_range(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, float* seconds_out, uint64_t* rays_out) {
     int rc = crt_render_launch(sc, buf, first_sample, samples, 0);
     if (rc != CRT_OK) return rc;
@@ -792,11 +934,16 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
     A.v = A.u + n;
     A.front = reinterpret_cast<int32_t*>(A.v + n);
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    switch (sc->stack_entries) {
-    case 8: hipLaunchKernelGGL((trace_primary_kernel<8>), grid, dim3(kBlock), 0, sc->stream, A); break;
-    case 16: hipLaunchKernelGGL((trace_primary_kernel<16>), grid, dim3(kBlock), 0, sc->stream, A); break;
-    case 32: hipLaunchKernelGGL((trace_primary_kernel<32>), grid, dim3(kBlock), 0, sc->stream, A); break;
-    default: hipLaunchKernelGGL((trace_primary_kernel<64>), grid, dim3(kBlock), 0, sc->stream, A); break;
+    A.flat_boxes = sc->flat_boxes; A.flat_prims = sc->flat_prims; A.flat_obj = sc->flat_obj; A.flat_count = sc->flat_count;
+    if (kernel_mode(sc) == kModeFlat) {
+        hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0>), grid, dim3(kBlock), (size_t)sc->lds_flat_bytes, sc->stream, A);
+    } else {
+        switch (sc->stack_entries) {
+        case 8: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A); break;
+        case 16: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A); break;
+        case 32: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 32>), grid, dim3(kBlock), 32 * kBlock * 4, sc->stream, A); break;
+        default: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 64>), grid, dim3(kBlock), 64 * kBlock * 4, sc->stream, A); break;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);

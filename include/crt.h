@@ -218,8 +218,15 @@ void* crt_scene_stream(crt_scene* sc);
  * kernel(s) and the pass-resolve kernel, in milliseconds. */
 int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms);
 
-/* Kernel selection: 0 = fused persistent kernel (default), 1 = wavefront pipeline with
- * per-bounce queue compaction.  Both produce the same image. */
+/* Development aid: loop-occupancy counters of a library built with -DCRT_PROFILE
+ * (32 values: site k -> [2k] wave-level executions, [2k+1] active lanes).  The product build
+ * returns CRT_ERR_UNSUPPORTED. */
+int crt_profile_counters(uint64_t* out32, int reset);
+
+/* How the kernels reach the geometry: 0 = automatic (default), 1 = BVH4 walk with the scene in
+ * HBM, 2 = BVH4 walk over an LDS copy of the scene (small scenes), 3 = flat box loop with a
+ * per-lane candidate mask (at most 64 objects).  A mode the scene does not qualify for falls
+ * back to the next one.  All modes produce the same image. */
 int crt_scene_set_mode(crt_scene* sc, int mode);
 
 /* Primary-ray probe used by the parity tests: for every pixel trace the camera ray of

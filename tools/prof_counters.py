@@ -1,0 +1,23 @@
+"""Loop-occupancy report from the -DCRT_PROFILE build: CRT_LIB=cudaraytracer_amd/libcrt_hip_prof.so python tools/prof_counters.py [scene]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import cudaraytracer_amd as crt
+from cudaraytracer_amd import api
+name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
+sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name))
+if len(sys.argv) > 2:
+    sc.set_render(samples=int(sys.argv[2]))
+buf = crt.create_buffer(sc)
+lib = crt.lib()
+assert lib.crt_profile_counters(None, 1) == 0, lib.crt_last_error()
+secs = crt.render(sc, buf)
+out = np.zeros(32, np.uint64)
+lib.crt_profile_counters(out.ctypes.data, 0)
+rays = api.last_ray_count
+names = ["outer", "regen", "trace", "node", "prim", "shade", "reject", "xform", "push"]
+print(f"{name}: rays {rays}")
+for k, n in enumerate(names):
+    w, l = int(out[2 * k]), int(out[2 * k + 1])
+    if w:
+        print(f"{n:8s} wave-execs {w:12d}  lanes {l:14d}  util {l / (64.0 * w):6.3f}  wave-execs/ray*64 {w * 64.0 / rays:7.3f}  lanes/ray {l / rays:7.3f}")
