@@ -329,53 +329,179 @@ __device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, 
 }
 
 // ------------------------------------------------------------------ flat traversal ------
-// Small scenes (at most 64 objects).  The reference's traversal never sorts children by
-// distance, so the order in which leaf slots are visited is a fixed depth-first order that does
-// not depend on the ray (bvh.cuh:387-419: slots 0..3 in order, pushed children popped last-in
-// first-out).  The host lays the leaf slots out in exactly that order ("entries").  A ray then
-//   1. runs the slab test against every entry's box in a loop that is UNIFORM across the wave:
-//      box data comes through scalar loads from the constant address space, there is no stack,
-//      no per-lane addressing and no divergence, and sets one bit per entry whose box it hits;
-//   2. tests its candidate primitives in entry order, one per round, with the shrinking interval.
-// This visits a superset of the boxes the tree walk visits (the inner boxes of a 36-triangle
-// tree reject almost nothing: 31 box tests per ray through the tree, 36 here) but removes all
-// traversal divergence, which costs a 64-wide wave far more than the few extra tests.
-// Result: same closest hit, same tie resolution (entry order = reference visiting order; the
-// slab test of step 1 uses the open interval [tmin, inf) and step 2 re-applies the interval test
-// exactly as the reference's primitive test does).
+// Small scenes (at most 64 box slots).  Measured on the 36-triangle Cornell box, the tree walk
+// spends its time on divergence, not on arithmetic: the inner boxes reject almost nothing
+// (31 box tests per ray through the tree against 36 leaves) while lanes sit on different
+// nodes and reach leaves at different times (8-20 % of the lanes active in the primitive
+// tests).  The flat mode removes the tree from the inner loop:
+//
+//   1. BOX PHASE, uniform across the wave.  Every box slot is tested by every lane in one
+//      loop whose box data comes through scalar loads (constant address space); there is no
+//      stack, no per-lane addressing, no divergence.  A hit sets one bit in the lane's mask.
+//   2. PRIMITIVE PHASE.  Each lane walks its set bits; one round of the loop tests one slot
+//      per lane.
+//
+// What a slot is.  Triangles that share a bit-identical box and transform are paired (a quad
+// is two such triangles, and quads/boxes are what scenes here are made of), so one box test
+// and one round cover both.  Triangles under a rotation get their box in OBJECT space (tight
+// slab, padded) and are tested with the ray transformed once per rotation ("group") instead
+// of the world-space box of the rotated slab, which for a rotated cube face is almost the
+// whole cube: that alone cuts the candidates of a ray that passes a rotated block from up to
+// 12 to about 2.  Everything else (untransformed triangles, spheres) keeps the world box the
+// reference stores in its BVH slot.
+//
+// Same result as the reference's ordered walk.  The closest hit does not depend on the order
+// of the tests except when two candidates have exactly the same t.  The reference visits leaf
+// slots in a fixed depth-first order that does not depend on the ray (bvh.cuh:387-419: slots
+// 0..3 in order, children popped last-in first-out), accepts a triangle on the closed interval
+// (hittable.cuh:335) and a sphere on the open one (:287-289).  So with `rank` = position of a
+// primitive in that order, "tested later wins a tie if it is a triangle, never if it is a
+// sphere" reproduces the reference's choice in any test order; it is applied in consider().
 typedef float NativeQuad __attribute__((ext_vector_type(4)));
 typedef const NativeQuad __attribute__((address_space(4))) * ConstQuadPtr;
+typedef const float __attribute__((address_space(4))) * ConstFloatPtr;
+typedef float NativePair __attribute__((ext_vector_type(2)));
 
-struct FlatBoxes {
-    ConstQuadPtr quads;   // [count][2]: {minx, maxx, miny, maxy}, {minz, maxz, 0, 0}
-    int count;
+constexpr int kSlotQuads = 5;          // float4 per slot record of the primitive phase
+constexpr int kMaxFlatSlots = 64;
+constexpr int kMaxFlatGroups = 2;      // rotations that get their own object-space group
+
+struct FlatView {                      // part of the kernel arguments
+    const float4* boxes;               // [slot_count][2]: {minx,maxx,miny,maxy},{minz,maxz,0,0}
+    const float4* slots;               // [slot_count][5]: see pack_slot() on the host
+    const int32_t* ent_obj;            // rank in the reference's visiting order -> object index
+    const float* group_xf;             // [groups][24] transform of group 1.. (rinv, anchor, trans, rot)
+    int32_t slot_count;
+    int32_t group_end[kMaxFlatGroups + 1];   // slots [0,e0) world, [e0,e1) group 1, [e1,e2) group 2
+    int32_t groups;
 };
 
-template <class Mem>
-__device__ __forceinline__ Hit traverse_flat(const Mem& S, const FlatBoxes& F, const Ray& r, float tmin, float tmax) {
-    const float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;     // aabb.cuh:140
-    const float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
-    const float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
-    unsigned long long cand = 0;
-    for (int e = 0; e < F.count; e++) {
-        const NativeQuad b0 = F.quads[2 * e], b1 = F.quads[2 * e + 1];
-        // For a non-empty box min <= max, so the reference's swap on a negative reciprocal
-        // (aabb.cuh:144-148) selects exactly fmin/fmax of the two plane distances.
-        const float ax = (b0.x - r.o.x) * ix, bx = (b0.y - r.o.x) * ix;
-        const float ay = (b0.z - r.o.y) * iy, by = (b0.w - r.o.y) * iy;
-        const float az = (b1.x - r.o.z) * iz, bz = (b1.y - r.o.z) * iz;
-        const float lo = fmaxf(fmaxf(fmaxf(tmin, fminf(ax, bx)), fminf(ay, by)), fminf(az, bz));
-        const float hi = fminf(fminf(fminf(tmax, fmaxf(ax, bx)), fmaxf(ay, by)), fmaxf(az, bz));
-        if (!(hi < lo)) cand |= 1ull << e;
+struct FlatLds {
+    const float4* slots;               // [5][slot_count] field-major copy in LDS
+    const float* xforms;               // transforms of world-group primitives that carry one
+    int slot_count;
+};
+
+// One slab test of the box phase; 1 when the box is hit on [tmin, +inf).
+// For a non-empty box min <= max, so the reference's swap on a negative reciprocal
+// (aabb.cuh:144-148) selects exactly fmin/fmax of the two plane distances.
+__device__ __forceinline__ unsigned flat_box_hit(NativeQuad b0, NativeQuad b1, V3 o, V3 inv, float tmin) {
+    const float ax = (b0.x - o.x) * inv.x, bx = (b0.y - o.x) * inv.x;
+    const float ay = (b0.z - o.y) * inv.y, by = (b0.w - o.y) * inv.y;
+    const float az = (b1.x - o.z) * inv.z, bz = (b1.y - o.z) * inv.z;
+    const float lo = fmaxf(tmin, fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)));
+    const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return (hi < lo) ? 0u : 1u;
+}
+__device__ __forceinline__ V3 slab_reciprocal(V3 d) {                       // aabb.cuh:140
+    return v3((fabsf(d.x) > 1e-12f) ? (1.0f / d.x) : 1e8f, (fabsf(d.y) > 1e-12f) ? (1.0f / d.y) : 1e8f,
+              (fabsf(d.z) > 1e-12f) ? (1.0f / d.z) : 1e8f);
+}
+// Box tests of slots [first, last) -> bits shifted into (hi:lo) from the right, so that slot s
+// ends up at bit (slot_count-1-s): the first slot is the highest set bit.
+__device__ __forceinline__ void flat_box_range(ConstQuadPtr boxes, int first, int last, V3 o, V3 inv, float tmin,
+                                               unsigned& lo_word, unsigned& hi_word) {
+#pragma unroll 4
+    for (int s = first; s < last; s++) {
+        const unsigned hit = flat_box_hit(boxes[2 * s], boxes[2 * s + 1], o, inv, tmin);
+        hi_word = (hi_word << 1) | (lo_word >> 31);
+        lo_word = (lo_word << 1) | hit;
     }
+}
+
+struct TriEval {
+    bool ok;
+    float t, u, v;
+};
+// hit_tri (hittable.cuh:314-335) without early exits: same tests, same arithmetic.
+__device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax) {
+    TriEval r;
+    V3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    bool ok = !(fabsf(det) < 1e-8f);
+    float inv_det = 1.0f / det;
+    V3 tvec = o - point;
+    r.u = dot(tvec, pvec) * inv_det;
+    ok = ok && !(r.u < 0.0f || r.u > 1.0f);
+    V3 qvec = cross(tvec, e1);
+    r.v = dot(d, qvec) * inv_det;
+    ok = ok && !(r.v < 0.0f || r.u + r.v > 1.0f);
+    r.t = dot(e2, qvec) * inv_det;
+    r.ok = ok && (tmin <= r.t && r.t <= tmax);
+    return r;
+}
+
+// Order-independent form of "if (hit(r, [tmin, closest])) closest = rec.t" (bvh.cuh:407-411).
+__device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, float t, int rank, bool is_tri, float bu, float bv) {
+    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? is_tri : !best_tri);
+    if (ok && (t < best.t || (t == best.t && win_tie))) {
+        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_tri = is_tri;
+    }
+}
+
+template <int GROUPS>
+__device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax) {
+    ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
+    ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
+    unsigned cand_lo = 0, cand_hi = 0;
+    flat_box_range(boxes, 0, F.group_end[0], r.o, slab_reciprocal(r.d), tmin, cand_lo, cand_hi);
+    // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
+    V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
+    if constexpr (GROUPS >= 1) {
+        float X[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) X[k] = gx[k];
+        to_object_space(X, r.o, r.d, o1, d1);
+        flat_box_range(boxes, F.group_end[0], F.group_end[1], o1, slab_reciprocal(d1), tmin, cand_lo, cand_hi);
+    }
+    if constexpr (GROUPS >= 2) {
+        float X[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) X[k] = gx[kXformFloats + k];
+        to_object_space(X, r.o, r.d, o2, d2);
+        flat_box_range(boxes, F.group_end[1], F.group_end[2], o2, slab_reciprocal(d2), tmin, cand_lo, cand_hi);
+    }
+
     Hit best;
     best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
-    while (cand) {
+    bool best_tri = false;
+    const int n = L.slot_count;
+    while (cand_lo | cand_hi) {
         CRT_PROF(kProfPrim);
-        const int e = __builtin_ctzll(cand);
-        cand &= cand - 1;
-        float t, bu, bv;
-        if (prim_test(S, e, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = e; best.bu = bu; best.bv = bv; }
+        int bit;
+        if (cand_hi) { bit = 63 - __builtin_clz(cand_hi); cand_hi &= ~(1u << (bit - 32)); }
+        else { bit = 31 - __builtin_clz(cand_lo); cand_lo &= ~(1u << bit); }
+        const int s = n - 1 - bit;
+        const float4 q0 = L.slots[0 * n + s], q1 = L.slots[1 * n + s], q2 = L.slots[2 * n + s];
+        const float4 q3 = L.slots[3 * n + s], q4 = L.slots[4 * n + s];
+        const int meta = __float_as_int(q4.z), xf = __float_as_int(q4.w);
+        const int rank_a = meta & 63, rank_b = (meta >> 6) & 63, group = (meta >> 15) & 3;
+        const bool has_b = (meta >> 12) & 1, is_tri = ((meta >> 13) & 3) == 2;
+        V3 o = r.o, d = r.d;
+        if constexpr (GROUPS >= 1) { if (group == 1) { o = o1; d = d1; } }
+        if constexpr (GROUPS >= 2) { if (group == 2) { o = o2; d = d2; } }
+        if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(L.xforms + xf * kXformFloats, r.o, r.d, o, d); }
+        if (is_tri) {
+            // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
+            TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax);
+            TriEval B = tri_eval(o, d, v3(q0.y, q0.w, q1.y), v3(q1.w, q2.y, q2.w), v3(q3.y, q3.w, q4.y), tmin, tmax);
+            consider(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
+            consider(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
+        } else {
+            // sphere slot: {c0.xyz, radius} {cd.xyz, 0}.  The root the reference would take does not
+            // depend on the upper bound: the near root if it is beyond tmin, else the far one.
+            V3 center = v3(q0.x, q0.y, q0.z) + v3(q1.x, q1.y, q1.z) * r.time;
+            V3 oc = o - center;
+            float a = length_squared(d);
+            float h = dot(oc, d);
+            float c = length_squared(oc) - q0.w * q0.w;
+            float disc = h * h - a * c;
+            float sq = sqrtf(disc);
+            float r1 = (-h - sq) / a, r2 = (-h + sq) / a;
+            float root = (tmin < r1 && r1 < tmax) ? r1 : r2;
+            bool ok = !(disc < 0.0f) && (tmin < root && root < tmax);
+            consider(best, best_tri, ok, root, rank_a, false, 0.0f, 0.0f);
+        }
     }
     return best;
 }

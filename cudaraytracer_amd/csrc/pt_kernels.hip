@@ -36,15 +36,12 @@ constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth o
 enum : int {
     kModeTreeGlobal = 0,   // BVH4 walk, node/primitive records read from HBM through L1/L2
     kModeTreeLds = 1,      // BVH4 walk over a field-major copy of the scene in LDS
-    kModeFlat = 2          // <= 64 objects: wave-uniform box loop + per-lane candidate mask
+    kModeFlat = 2          // <= 64 box slots: wave-uniform box loop + per-lane candidate mask
 };
 
 struct RenderArgs {
     DevScene sc;
-    const float4* flat_boxes;        // [flat_count][2], entry = leaf slot in reference visiting order
-    const float4* flat_prims;        // [flat_count][3] primitive records in entry order
-    const int32_t* flat_obj;         // entry -> object index
-    int flat_count;
+    FlatView flat;                   // small-scene box slots (flat mode)
     float* partial;                  // [chunks][14][pix_padded]  chunk sums, tile-major pixels
     unsigned long long* ray_counter;
     int tiles_x, tiles_y, ntiles, pix_padded;
@@ -80,10 +77,24 @@ __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int 
     return m;
 }
 
+// Flat mode: slot records (field-major) and the transforms of world-group primitives.
+__device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const float* xforms, int nx, float4* lds) {
+    const int n = F.slot_count;
+    float* lx = reinterpret_cast<float*>(lds + kSlotQuads * n);
+    for (int i = threadIdx.x; i < n * kSlotQuads; i += kBlock) {
+        int slot = i / kSlotQuads, q = i - slot * kSlotQuads;
+        lds[q * n + slot] = F.slots[i];
+    }
+    for (int i = threadIdx.x; i < nx * kXformFloats; i += kBlock) lx[i] = xforms[i];
+    FlatLds L;
+    L.slots = lds; L.xforms = lx; L.slot_count = n;
+    return L;
+}
+
 // LDS carve-up of a block: [pass sums: waves x 14 x 64 floats][stacks: STACK x 256 ints][scene copy]
 constexpr int kAccFloatsPerWave = kPasses * 64;
 
-template <int MODE, int STACK>
+template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
     extern __shared__ float4 smem[];
     float* acc_all = reinterpret_cast<float*>(smem);
@@ -100,11 +111,9 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
     SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms;
     SceneLds SL = {};
     if constexpr (MODE == kModeTreeLds) SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene);
-    if constexpr (MODE == kModeFlat) SL = stage_scene_in_lds(sc.nodes, 0, A.flat_prims, A.flat_count, sc.xforms, sc.xform_count, lds_scene);
+    FlatLds FL = {};
+    if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
-    FlatBoxes FB;
-    FB.quads = (ConstQuadPtr)A.flat_boxes;
-    FB.count = A.flat_count;
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
     if (tile >= A.ntiles) return;
@@ -163,12 +172,12 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
             rays++;
             CRT_PROF(kProfTrace);
             Hit h;
-            if constexpr (MODE == kModeFlat) h = traverse_flat(SL, FB, ray, 0.001f, INFINITY);
+            if constexpr (MODE == kModeFlat) h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY);
             else if constexpr (MODE == kModeTreeLds) h = traverse(SL, ray, 0.001f, INFINITY, stk);
             else h = traverse(SG, ray, 0.001f, INFINITY, stk);    // render.cuh:47
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
-                if constexpr (MODE == kModeFlat) h.obj = A.flat_obj[h.obj];
+                if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
                 Surface sf = make_surface(sc, ray, h);
                 V3 attenuation;
                 Ray next;
@@ -265,23 +274,20 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
 // Bounce-0 closest hit per pixel for the parity tables.
 struct PrimaryArgs {
     DevScene sc;
-    const float4* flat_boxes;
-    const float4* flat_prims;
-    const int32_t* flat_obj;
-    int flat_count;
+    FlatView flat;
     int sample;
     int32_t* obj;
     float *t, *u, *v;
     int32_t* front;
 };
-template <int MODE, int STACK>
+template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     extern __shared__ float4 smem[];
     int* stack_mem = reinterpret_cast<int*>(smem);
     float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
     const DevScene& sc = A.sc;
-    SceneLds SL = {};
-    if constexpr (MODE == kModeFlat) SL = stage_scene_in_lds(sc.nodes, 0, A.flat_prims, A.flat_count, sc.xforms, sc.xform_count, lds_scene);
+    FlatLds FL = {};
+    if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= sc.width * sc.height) return;
@@ -291,11 +297,8 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     Ray ray = camera_ray(sc.cam, pi, pj, rng);
     Hit h;
     if constexpr (MODE == kModeFlat) {
-        FlatBoxes FB;
-        FB.quads = (ConstQuadPtr)A.flat_boxes;
-        FB.count = A.flat_count;
-        h = traverse_flat(SL, FB, ray, 0.001f, INFINITY);
-        if (h.obj >= 0) h.obj = A.flat_obj[h.obj];
+        h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY);
+        if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
     } else {
         SceneGlobal S;
         S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms;
@@ -329,12 +332,9 @@ struct crt_scene {
     crt_render_info render = {};
     int stack_entries = 8;
     int lds_scene_bytes = 0;         // field-major copy of nodes + prims + xforms
-    int lds_flat_bytes = 0;          // flat mode: prims in entry order + xforms
+    int lds_flat_bytes = 0;          // flat mode: slot records + xforms
     bool can_lds = false, can_flat = false;
-    const float4* flat_boxes = nullptr;
-    const float4* flat_prims = nullptr;
-    const int32_t* flat_obj = nullptr;
-    int flat_count = 0;
+    FlatView flat = {};
     int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
     float* partial = nullptr;
     size_t partial_bytes = 0;
@@ -475,9 +475,9 @@ int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)STACK * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
-        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
     } else {
-        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
     }
     CRT_HIP(hipGetLastError());
     return CRT_OK;
@@ -487,7 +487,11 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
     const int mode = kernel_mode(sc);
     if (mode == kModeFlat) {
         size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)sc->lds_flat_bytes;
-        hipLaunchKernelGGL((render_fused<kModeFlat, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+        switch (sc->flat.groups) {
+        case 0: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        case 1: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        default: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 2>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        }
         CRT_HIP(hipGetLastError());
         return CRT_OK;
     }
@@ -620,21 +624,91 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         }
     }
 
-    // flat list for small scenes
+    // ---- flat mode (small scenes): box slots, see pt_device.h "flat traversal"
     std::vector<int> leaf_slots;
     reference_visit_order(d->bvh, leaf_slots);
-    const bool can_flat = !leaf_slots.empty() && leaf_slots.size() <= 64;
-    std::vector<float> flat_box_rec, flat_prim_rec;
-    std::vector<int32_t> flat_obj_rec;
+    std::vector<float> flat_box_rec, flat_slot_rec, flat_group_xf;
+    std::vector<int32_t> flat_ent_obj;
+    int flat_groups = 0, flat_group_end[kMaxFlatGroups + 1] = {0, 0, 0};
+    bool can_flat = !leaf_slots.empty() && leaf_slots.size() <= 64;
     if (can_flat) {
-        for (int s : leaf_slots) {
-            const float* mn = d->bvh.min_bounds + 3 * s;
-            const float* mx = d->bvh.max_bounds + 3 * s;
-            const float rec[8] = {mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], 0.0f, 0.0f};
-            flat_box_rec.insert(flat_box_rec.end(), rec, rec + 8);
-            int o = d->bvh.object_index[s];
-            flat_obj_rec.push_back(o);
-            flat_prim_rec.insert(flat_prim_rec.end(), &prim_rec[(size_t)o * kPrimQuads * 4], &prim_rec[(size_t)(o + 1) * kPrimQuads * 4]);
+        struct Slot {
+            int group, xf, type, rank_a, rank_b;
+            bool has_b;
+            float box[6];     // min xyz, max xyz
+        };
+        std::vector<Slot> slots;
+        std::vector<int> group_of_xf;      // rotation transform index -> group number (1..)
+        for (size_t rank = 0; rank < leaf_slots.size() && can_flat; rank++) {
+            const int ls = leaf_slots[rank];
+            const int oi = d->bvh.object_index[ls];
+            const crt_object& o = d->objects[oi];
+            flat_ent_obj.push_back(oi);
+            const int xf = __builtin_bit_cast(int32_t, prim_rec[(size_t)oi * kPrimQuads * 4 + 9]);
+            Slot sl;
+            sl.group = 0; sl.xf = xf; sl.type = o.type; sl.rank_a = (int)rank; sl.rank_b = 0; sl.has_b = false;
+            for (int a = 0; a < 3; a++) { sl.box[a] = d->bvh.min_bounds[3 * ls + a]; sl.box[3 + a] = d->bvh.max_bounds[3 * ls + a]; }
+            const bool rotated = !(identity9(o.rotation) && identity9(o.rotation_inv));
+            if (o.type == CRT_OBJ_TRI && xf >= 0 && rotated) {
+                // own group per rotation; object-space box of the three vertices, padded
+                int g = 0;
+                for (size_t k = 0; k < group_of_xf.size(); k++)
+                    if (group_of_xf[k] == xf) g = (int)k + 1;
+                if (!g) {
+                    if ((int)group_of_xf.size() == kMaxFlatGroups) { can_flat = false; break; }
+                    group_of_xf.push_back(xf);
+                    g = (int)group_of_xf.size();
+                }
+                sl.group = g;
+                sl.xf = -1;
+                for (int a = 0; a < 3; a++) {
+                    const float v0 = o.p0[a], v1 = o.p0[a] + o.p1[a], v2 = o.p0[a] + o.p2[a];
+                    const float lo = std::fmin(v0, std::fmin(v1, v2)), hi = std::fmax(v0, std::fmax(v1, v2));
+                    const float pad = 0.001f + 1e-5f * (std::fabs(lo) + std::fabs(hi));
+                    sl.box[a] = lo - pad;
+                    sl.box[3 + a] = hi + pad;
+                }
+            }
+            bool merged = false;
+            if (o.type == CRT_OBJ_TRI) {
+                for (Slot& other : slots) {
+                    if (!other.has_b && other.type == CRT_OBJ_TRI && other.group == sl.group && other.xf == sl.xf &&
+                        !std::memcmp(other.box, sl.box, sizeof(sl.box))) {
+                        other.has_b = true;
+                        other.rank_b = (int)rank;
+                        merged = true;
+                        break;
+                    }
+                }
+            }
+            if (!merged) slots.push_back(sl);
+        }
+        can_flat = can_flat && (int)slots.size() <= kMaxFlatSlots;
+        if (can_flat) {
+            flat_groups = (int)group_of_xf.size();
+            std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.group < b.group; });
+            for (const Slot& sl : slots) flat_group_end[sl.group] += 1;
+            for (int g = 1; g <= kMaxFlatGroups; g++) flat_group_end[g] += flat_group_end[g - 1];
+            for (int g : group_of_xf) flat_group_xf.insert(flat_group_xf.end(), &xforms[(size_t)g * kXformFloats], &xforms[(size_t)(g + 1) * kXformFloats]);
+            for (const Slot& sl : slots) {
+                const float brec[8] = {sl.box[0], sl.box[3], sl.box[1], sl.box[4], sl.box[2], sl.box[5], 0.0f, 0.0f};
+                flat_box_rec.insert(flat_box_rec.end(), brec, brec + 8);
+                float rec[kSlotQuads * 4] = {0};
+                const crt_object& A = d->objects[flat_ent_obj[sl.rank_a]];
+                const crt_object& B = d->objects[flat_ent_obj[sl.has_b ? sl.rank_b : sl.rank_a]];
+                if (sl.type == CRT_OBJ_TRI) {
+                    const float* fa[9] = {&A.p0[0], &A.p0[1], &A.p0[2], &A.p1[0], &A.p1[1], &A.p1[2], &A.p2[0], &A.p2[1], &A.p2[2]};
+                    const float* fb[9] = {&B.p0[0], &B.p0[1], &B.p0[2], &B.p1[0], &B.p1[1], &B.p1[2], &B.p2[0], &B.p2[1], &B.p2[2]};
+                    for (int k = 0; k < 9; k++) { rec[2 * k] = *fa[k]; rec[2 * k + 1] = *fb[k]; }
+                } else {
+                    rec[0] = A.p0[0]; rec[1] = A.p0[1]; rec[2] = A.p0[2]; rec[3] = A.p2[0];
+                    rec[4] = A.p1[0]; rec[5] = A.p1[1]; rec[6] = A.p1[2];
+                }
+                const int32_t meta = sl.rank_a | (sl.rank_b << 6) | ((sl.has_b ? 1 : 0) << 12) | (sl.type << 13) | (sl.group << 15);
+                rec[18] = as_float(meta);
+                rec[19] = as_float(sl.xf);
+                flat_slot_rec.insert(flat_slot_rec.end(), rec, rec + kSlotQuads * 4);
+            }
         }
     }
 
@@ -667,8 +741,9 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     size_t off_texs = blob.add(tex_rec.data(), tex_rec.size() * 4);
     size_t off_img = blob.add(images.data(), images.size() * sizeof(DevImage));
     size_t off_fbox = blob.add(flat_box_rec.data(), flat_box_rec.size() * 4);
-    size_t off_fprim = blob.add(flat_prim_rec.data(), flat_prim_rec.size() * 4);
-    size_t off_fobj = blob.add(flat_obj_rec.data(), flat_obj_rec.size() * 4);
+    size_t off_fslot = blob.add(flat_slot_rec.data(), flat_slot_rec.size() * 4);
+    size_t off_fobj = blob.add(flat_ent_obj.data(), flat_ent_obj.size() * 4);
+    size_t off_fgx = blob.add(flat_group_xf.data(), flat_group_xf.size() * 4);
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
@@ -704,11 +779,14 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
     sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + kWaves * kAccFloatsPerWave * 4 <= 40 * 1024;
     sc->can_flat = can_flat;
-    sc->flat_count = can_flat ? (int)leaf_slots.size() : 0;
-    sc->lds_flat_bytes = (int)((size_t)sc->flat_count * kPrimQuads * 16 + xforms.size() * 4);
-    sc->flat_boxes = reinterpret_cast<const float4*>(base + off_fbox);
-    sc->flat_prims = reinterpret_cast<const float4*>(base + off_fprim);
-    sc->flat_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
+    sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
+    sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
+    sc->flat.ent_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
+    sc->flat.group_xf = reinterpret_cast<const float*>(base + off_fgx);
+    sc->flat.slot_count = can_flat ? (int)(flat_box_rec.size() / 8) : 0;
+    for (int g = 0; g <= kMaxFlatGroups; g++) sc->flat.group_end[g] = flat_group_end[g];
+    sc->flat.groups = flat_groups;
+    sc->lds_flat_bytes = (int)((size_t)sc->flat.slot_count * kSlotQuads * 16 + xforms.size() * 4);
     if (const char* e = std::getenv("CRT_MODE")) sc->mode = std::atoi(e);
     *out = sc;
     return CRT_OK;
@@ -807,7 +885,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     chunks = (samples + A.chunk_size - 1) / A.chunk_size;
     A.first_sample = first_sample;
     A.samples = samples;
-    A.flat_boxes = sc->flat_boxes; A.flat_prims = sc->flat_prims; A.flat_obj = sc->flat_obj; A.flat_count = sc->flat_count;
+    A.flat = sc->flat;
     size_t need = (size_t)chunks * kPasses * A.pix_padded * sizeof(float);
     if (need > sc->partial_bytes) {
         if (sc->partial) CRT_HIP(hipFree(sc->partial));
@@ -934,15 +1012,20 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
     A.v = A.u + n;
     A.front = reinterpret_cast<int32_t*>(A.v + n);
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    A.flat_boxes = sc->flat_boxes; A.flat_prims = sc->flat_prims; A.flat_obj = sc->flat_obj; A.flat_count = sc->flat_count;
+    A.flat = sc->flat;
     if (kernel_mode(sc) == kModeFlat) {
-        hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0>), grid, dim3(kBlock), (size_t)sc->lds_flat_bytes, sc->stream, A);
+        const size_t lds = (size_t)sc->lds_flat_bytes;
+        switch (sc->flat.groups) {
+        case 0: hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        case 1: hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        default: hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0, 2>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        }
     } else {
         switch (sc->stack_entries) {
-        case 8: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A); break;
-        case 16: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A); break;
-        case 32: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 32>), grid, dim3(kBlock), 32 * kBlock * 4, sc->stream, A); break;
-        default: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 64>), grid, dim3(kBlock), 64 * kBlock * 4, sc->stream, A); break;
+        case 8: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A); break;
+        case 16: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16, 0>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A); break;
+        case 32: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 32, 0>), grid, dim3(kBlock), 32 * kBlock * 4, sc->stream, A); break;
+        default: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 64, 0>), grid, dim3(kBlock), 64 * kBlock * 4, sc->stream, A); break;
         }
     }
     hipError_t e = hipGetLastError();
