@@ -28,6 +28,9 @@
 
 namespace crt {
 
+#ifndef CRT_FUSED_WAVES_PER_SIMD
+#define CRT_FUSED_WAVES_PER_SIMD 4    // register budget of render_fused: 512 / 4 = 128 VGPRs
+#endif
 constexpr int kBlock = 256;          // 4 waves; one 8x8 pixel tile per wave
 constexpr int kWaves = kBlock / 64;
 constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
@@ -91,11 +94,21 @@ __device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const fl
     return L;
 }
 
+// Adds a finished path's contribution to the tile sums.  Adding an exact zero cannot change a
+// sum (sums start at +0 and x + 0 == x for every x including NaN), so zeros are skipped: most
+// contributions of short paths are zero (black environment, non-emitting first hit).
+__device__ __forceinline__ void acc_add(float* acc, int plane, int pix, float v) {
+    if (v != 0.0f) atomicAdd(&acc[plane * 64 + pix], v);
+}
+__device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
+    acc_add(acc, plane, pix, v.x); acc_add(acc, plane + 1, pix, v.y); acc_add(acc, plane + 2, pix, v.z);
+}
+
 // LDS carve-up of a block: [pass sums: waves x 14 x 64 floats][stacks: STACK x 256 ints][scene copy]
 constexpr int kAccFloatsPerWave = kPasses * 64;
 
 template <int MODE, int STACK, int GROUPS>
-__global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
     extern __shared__ float4 smem[];
     float* acc_all = reinterpret_cast<float*>(smem);
     int* stack_mem = reinterpret_cast<int*>(acc_all + kWaves * kAccFloatsPerWave);
@@ -185,9 +198,9 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
                     if (bounces == 0) {
                         pend_albedo = attenuation;
                         V3 n = unit(sf.normal);
-                        atomicAdd(&acc[9 * 64 + pix], n.x); atomicAdd(&acc[10 * 64 + pix], n.y); atomicAdd(&acc[11 * 64 + pix], n.z);
-                        atomicAdd(&acc[12 * 64 + pix], h.t * length(ray.d));
-                        atomicAdd(&acc[13 * 64 + pix], 1.0f);
+                        acc_add3(acc, 9, pix, n);
+                        acc_add(acc, 12, pix, h.t * length(ray.d));
+                        acc_add(acc, 13, pix, 1.0f);
                     }
                     throughput = throughput * attenuation;
                     ray = next;
@@ -196,28 +209,28 @@ __global__ __launch_bounds__(kBlock) void render_fused(RenderArgs A) {
                 } else {                                             // render.cuh:64-74
                     V3 emitted = emit(sc, sf);
                     V3 c = throughput * emitted;
-                    atomicAdd(&acc[0 * 64 + pix], c.x); atomicAdd(&acc[1 * 64 + pix], c.y); atomicAdd(&acc[2 * 64 + pix], c.z);
+                    acc_add3(acc, 0, pix, c);
                     V3 alb = pend_albedo;
                     if (bounces == 0) {
                         alb = emitted;
                         V3 n = unit(sf.normal);
-                        atomicAdd(&acc[6 * 64 + pix], emitted.x); atomicAdd(&acc[7 * 64 + pix], emitted.y); atomicAdd(&acc[8 * 64 + pix], emitted.z);
-                        atomicAdd(&acc[9 * 64 + pix], n.x); atomicAdd(&acc[10 * 64 + pix], n.y); atomicAdd(&acc[11 * 64 + pix], n.z);
-                        atomicAdd(&acc[12 * 64 + pix], h.t * length(ray.d));
-                        atomicAdd(&acc[13 * 64 + pix], 1.0f);
+                        acc_add3(acc, 6, pix, emitted);
+                        acc_add3(acc, 9, pix, n);
+                        acc_add(acc, 12, pix, h.t * length(ray.d));
+                        acc_add(acc, 13, pix, 1.0f);
                     }
-                    atomicAdd(&acc[3 * 64 + pix], alb.x); atomicAdd(&acc[4 * 64 + pix], alb.y); atomicAdd(&acc[5 * 64 + pix], alb.z);
+                    acc_add3(acc, 3, pix, alb);
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment(sc, ray.d);
-                atomicAdd(&acc[0 * 64 + pix], c.x); atomicAdd(&acc[1 * 64 + pix], c.y); atomicAdd(&acc[2 * 64 + pix], c.z);
+                acc_add3(acc, 0, pix, c);
                 V3 alb = pend_albedo;
                 if (bounces == 0) {
                     alb = c;
-                    atomicAdd(&acc[12 * 64 + pix], __builtin_nanf(""));
+                    atomicAdd(&acc[12 * 64 + pix], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
                 }
-                atomicAdd(&acc[3 * 64 + pix], alb.x); atomicAdd(&acc[4 * 64 + pix], alb.y); atomicAdd(&acc[5 * 64 + pix], alb.z);
+                acc_add3(acc, 3, pix, alb);
                 alive = false;
             }
         }
