@@ -152,6 +152,12 @@ class Scene:
             self._dev = h
         return self
 
+    def set_mode(self, mode):
+        """Geometry access path: 0 automatic, 1 BVH4 walk in HBM, 2 BVH4 walk in LDS, 3 flat slots."""
+        self.upload()
+        _check(_lib.crt_scene_set_mode(self._dev, int(mode)))
+        return self
+
     def get_device_scene(self):
         """scene::get_device_scene (scene.cuh:140): the device handle."""
         return self.upload()._dev

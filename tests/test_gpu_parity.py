@@ -16,10 +16,15 @@ def _desc_ptr(crt, sc):
     return crt.lib().crt_host_scene_desc(sc._host)
 
 
+MODES = {"auto": 0, "tree_hbm": 1, "tree_lds": 2}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name,size", [("cornell_box.yaml", 256), ("orthographic.yaml", 256)])
-def test_primary_hits_bit_exact(crt, oracle, name, size):
+def test_primary_hits_bit_exact(crt, oracle, name, size, mode):
     sc = crt.load_scene(scene_path(name))
     sc.set_render(size, size)
+    sc.set_mode(MODES[mode])
     for sample in (1, 7):
         g = sc.trace_primary(sample)
         o = oracle_lib.trace_primary(oracle, _desc_ptr(crt, sc), size, size, sample)
@@ -32,11 +37,13 @@ def test_primary_hits_bit_exact(crt, oracle, name, size):
     sc.close()
 
 
-def test_cornell_single_samples_bit_exact(crt, oracle):
+@pytest.mark.parametrize("mode", list(MODES))
+def test_cornell_single_samples_bit_exact(crt, oracle, mode):
     """Cornell touches only + - * / sqrt: with the shared RNG every sample must match bit for bit."""
     size = 128
     sc = crt.load_scene(scene_path("cornell_box.yaml"))
     sc.set_render(size, size, samples=64)
+    sc.set_mode(MODES[mode])
     buf = crt.create_buffer(sc)
     dp = _desc_ptr(crt, sc)
     ref = oracle_lib.new_passes(size, size)
