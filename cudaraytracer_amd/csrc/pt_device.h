@@ -63,6 +63,7 @@ struct DevImage {
 
 struct DevCamera {
     int32_t type;
+    int32_t needs_time;       // some sphere moves (center direction != 0)
     float defocus_angle;
     V3 center, llc, du, dv, w, defocus_u, defocus_v;
 };
@@ -101,6 +102,8 @@ struct Rng {
         uint32_t x = lowbias32(state + draws * 0x9E3779B9u);
         return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);
     }
+    // A draw whose value is never read only advances the counter.
+    __device__ __forceinline__ void skip(uint32_t n) { draws += n; }
     __device__ __forceinline__ V3 range3(float lo, float hi) {       // vec3::random(min,max) vec3.cuh:191
         float x = lo + (hi - lo) * uniform();
         float y = lo + (hi - lo) * uniform();
@@ -109,19 +112,6 @@ struct Rng {
     }
 };
 
-__device__ __forceinline__ V3 random_unit_vector(Rng& r) {            // vec3.cuh:204-212
-    while (true) {
-        CRT_PROF(kProfReject);
-        V3 p = r.range3(-1.0f, 1.0f);
-        float lensq = length_squared(p);
-        if (1e-30f < lensq && lensq <= 1.0f) return unit(p);
-    }
-}
-__device__ __forceinline__ V3 random_in_unit_sphere(Rng& r) {         // vec3.cuh:235-241
-    V3 p = r.range3(-1.0f, 1.0f);
-    while (length_squared(p) >= 1.0f) p = r.range3(-1.0f, 1.0f);
-    return p;
-}
 __device__ __forceinline__ void random_in_unit_disk(Rng& r, float& px, float& py) {   // vec3.cuh:249-255
     do {
         float a = r.uniform(), b = r.uniform();
@@ -136,8 +126,11 @@ struct Ray {
     float time;
 };
 __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rng& rng) {
-    V3 offset = rng.range3(-0.5f, 0.5f);            // sample_square: three draws, z unused (camera.cuh:93-96)
-    V3 on_plane = cam.llc + ((float)i + offset.x) * cam.du + ((float)j + offset.y) * cam.dv;
+    // sample_square draws three uniforms and uses two (camera.cuh:93-96)
+    const float offx = -0.5f + (0.5f - -0.5f) * rng.uniform();
+    const float offy = -0.5f + (0.5f - -0.5f) * rng.uniform();
+    rng.skip(1);
+    V3 on_plane = cam.llc + ((float)i + offx) * cam.du + ((float)j + offy) * cam.dv;
     Ray r;
     if (cam.type == 0) {                            // perspective_ray (camera.cuh:240-248)
         if (cam.defocus_angle <= 0.0f) {
@@ -152,7 +145,9 @@ __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rn
         r.o = on_plane;
         r.d = cam.w;
     }
-    r.time = rng.uniform();
+    // ray time (camera.cuh:246,264) is only read by moving spheres
+    if (cam.needs_time) r.time = rng.uniform();
+    else { r.time = 0.0f; rng.skip(1); }
     return r;
 }
 
@@ -658,14 +653,89 @@ __device__ __forceinline__ V3 refract(V3 uv, V3 n, float ni_over_nt) {          
 // (1-cos)^5 of the Schlick terms (material.cuh:152,186) as a multiplication chain.
 __device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 
-// material::scatter (material.cuh:359-372).  Returns false when the material does not
-// scatter (light, or a metal bounce that points into the surface).
-__device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const Surface& s, Rng& rng, V3& attenuation, Ray& out) {
-    float4 m0 = sc.mats[s.mat * 2];
+// Wave-cooperative form of the rejection samplers vec3::random_unit_vector (vec3.cuh:204-212,
+// in_sphere = false) and vec3::random_in_unit_sphere (vec3.cuh:235-241, in_sphere = true).
+//
+// A lane accepts its first candidate with probability pi/6, so a loop that runs until the last
+// of 64 lanes has accepted takes about 7 rounds with a quarter of the lanes active.  Candidate c
+// of a lane is a pure function of (rng.state, rng.draws + 3c), so ANY lane can evaluate it:
+// after every lane has tried its own first candidate, the lanes still pending publish their
+// stream position in LDS and all 64 lanes evaluate the next m candidates of each of them in
+// one round (m = 64 / pending, at most 8).  The pending lane takes the FIRST accepted candidate
+// in stream order and advances its counter by what the sequential loop would have consumed,
+// so the result and the draw count are identical to the sequential sampler's.
+// Must be called by the whole wave in uniform control flow; `pub` (128 words) and `res`
+// (192 floats) are this wave's LDS scratch.
+__device__ __forceinline__ V3 candidate_point(uint32_t state, uint32_t base) {
+    Rng r;
+    r.state = state; r.draws = base;
+    return r.range3(-1.0f, 1.0f);
+}
+__device__ __forceinline__ bool sample_accepted(V3 p, bool in_sphere) {
+    const float lensq = length_squared(p);
+    return in_sphere ? (lensq < 1.0f) : (1e-30f < lensq && lensq <= 1.0f);
+}
+__device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng& rng, volatile uint32_t* pub, volatile float* res, int lane) {
+    V3 out = v3(0.0f, 0.0f, 0.0f);
+    bool pending = false;
+    if (need) {
+        CRT_PROF(kProfReject);
+        out = candidate_point(rng.state, rng.draws);
+        rng.draws += 3;
+        pending = !sample_accepted(out, in_sphere);
+    }
+    unsigned long long mask = __ballot(pending);
+    while (mask) {                                          // wave-uniform
+        CRT_PROF(kProfReject);
+        const int pending_count = __builtin_popcountll(mask);
+        const int log2m = pending_count <= 8 ? 3 : (pending_count <= 16 ? 2 : (pending_count <= 32 ? 1 : 0));
+        const int m = 1 << log2m;
+        const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (pending) {
+            pub[2 * rank] = rng.state;
+            pub[2 * rank + 1] = rng.draws | (in_sphere ? 0x80000000u : 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int target = lane >> log2m, c = lane & (m - 1);
+        bool ok = false;
+        if (target < pending_count) {
+            const uint32_t st = pub[2 * target], word = pub[2 * target + 1];
+            const V3 p = candidate_point(st, (word & 0x7fffffffu) + 3u * (uint32_t)c);
+            ok = sample_accepted(p, (word >> 31) != 0);
+            res[3 * lane] = p.x; res[3 * lane + 1] = p.y; res[3 * lane + 2] = p.z;
+        }
+        const unsigned long long okmask = __ballot(ok);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (pending) {
+            const unsigned sub = (unsigned)(okmask >> (rank << log2m)) & ((1u << m) - 1u);
+            if (sub) {
+                const int first = __builtin_ctz(sub);
+                const int src = (rank << log2m) + first;
+                out = v3(res[3 * src], res[3 * src + 1], res[3 * src + 2]);
+                rng.draws += 3u * (uint32_t)(first + 1);
+                pending = false;
+            } else {
+                rng.draws += 3u * (uint32_t)m;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        mask = __ballot(pending);
+    }
+    if (need && !in_sphere) out = unit(out);
+    return out;
+}
+
+// material::scatter (material.cuh:359-372) with the sphere sample already drawn (see
+// coop_sphere_sample): `rv` is the random unit vector for a lambertian surface, the in-sphere
+// vector for a metal.  Returns false when the material does not scatter (light, or a metal
+// bounce that points into the surface).
+__device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, const Surface& s, float4 m0, V3 rv, Rng& rng, V3& attenuation, Ray& out) {
     int type = __float_as_int(m0.x);
     out.time = in.time;
     if (type == 0) {                                           // lambertian :290-297
-        V3 dir = s.normal + random_unit_vector(rng);
+        V3 dir = s.normal + rv;
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.normal;
         out.o = s.p + s.normal * 0.001f;
         out.d = dir;
@@ -677,7 +747,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const
         V3 unit_dir = unit(in.d);
         V3 reflected = reflect(unit_dir, s.normal);
         out.o = s.p;
-        out.d = reflected + m0.z * random_in_unit_sphere(rng);
+        out.d = reflected + m0.z * rv;
         float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
         V3 albedo = v3(m1.x, m1.y, m1.z);
         attenuation = albedo + (v3(1.0f, 1.0f, 1.0f) - albedo) * pow5(1.0f - cos_theta);
@@ -703,6 +773,7 @@ __device__ __forceinline__ bool scatter(const DevScene& sc, const Ray& in, const
     }
     return false;
 }
+
 // material::emit (material.cuh:375-381)
 __device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
     float4 m0 = sc.mats[s.mat * 2];

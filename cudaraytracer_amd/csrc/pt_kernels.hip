@@ -106,17 +106,22 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
 
 // LDS carve-up of a block: [pass sums: waves x 14 x 64 floats][stacks: STACK x 256 ints][scene copy]
 constexpr int kAccFloatsPerWave = kPasses * 64;
+constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
+constexpr int kWaveLdsBytes = (kAccFloatsPerWave + kCoopWordsPerWave) * 4;
 
 template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
     extern __shared__ float4 smem[];
     float* acc_all = reinterpret_cast<float*>(smem);
-    int* stack_mem = reinterpret_cast<int*>(acc_all + kWaves * kAccFloatsPerWave);
+    uint32_t* coop_all = reinterpret_cast<uint32_t*>(acc_all + kWaves * kAccFloatsPerWave);
+    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave);
     float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
     const DevScene& sc = A.sc;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* acc = acc_all + wave * kAccFloatsPerWave;              // [14][64] sums of this wave's tile
+    volatile uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
+    volatile float* coop_res = reinterpret_cast<volatile float*>(coop_pub + 128);
 #pragma unroll
     for (int k = 0; k < kPasses; k++) acc[k * 64 + lane] = 0.0f;
 
@@ -181,20 +186,32 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             if (next_item >= total_items) break;
             continue;
         }
+        Hit h;
+        h.t = 0.0f; h.obj = -1; h.bu = 0.0f; h.bv = 0.0f;
+        Surface sf = {};
+        float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int mat_type = -1;
         if (alive) {
             rays++;
             CRT_PROF(kProfTrace);
-            Hit h;
             if constexpr (MODE == kModeFlat) h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY);
             else if constexpr (MODE == kModeTreeLds) h = traverse(SL, ray, 0.001f, INFINITY, stk);
             else h = traverse(SG, ray, 0.001f, INFINITY, stk);    // render.cuh:47
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
-                Surface sf = make_surface(sc, ray, h);
+                sf = make_surface(sc, ray, h);
+                m0 = sc.mats[sf.mat * 2];
+                mat_type = __float_as_int(m0.x);
+            }
+        }
+        // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
+        const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
+        if (alive) {
+            if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
-                if (scatter(sc, ray, sf, rng, attenuation, next)) {  // render.cuh:52-61
+                if (scatter_with(sc, ray, sf, m0, rv, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         pend_albedo = attenuation;
                         V3 n = unit(sf.normal);
@@ -485,7 +502,7 @@ int kernel_mode(const crt_scene* sc) {
 
 template <int STACK>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
-    size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)STACK * kBlock * sizeof(int);
+    size_t lds = (size_t)kWaves * kWaveLdsBytes + (size_t)STACK * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
         hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
@@ -499,7 +516,7 @@ int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
     const int mode = kernel_mode(sc);
     if (mode == kModeFlat) {
-        size_t lds = (size_t)kWaves * kAccFloatsPerWave * 4 + (size_t)sc->lds_flat_bytes;
+        size_t lds = (size_t)kWaves * kWaveLdsBytes + (size_t)sc->lds_flat_bytes;
         switch (sc->flat.groups) {
         case 0: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A); break;
         case 1: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A); break;
@@ -783,6 +800,11 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     const crt_camera& c = d->camera;
     D.cam.type = c.type;
     D.cam.defocus_angle = c.defocus_angle;
+    D.cam.needs_time = 0;
+    for (int i = 0; i < d->object_count; i++) {
+        const crt_object& o = d->objects[i];
+        if (o.type != CRT_OBJ_TRI && !(o.p1[0] == 0.0f && o.p1[1] == 0.0f && o.p1[2] == 0.0f)) D.cam.needs_time = 1;
+    }
     D.cam.center = v3(c.center); D.cam.llc = v3(c.lower_left_corner);
     D.cam.du = v3(c.pixel_delta_u); D.cam.dv = v3(c.pixel_delta_v); D.cam.w = v3(c.w);
     D.cam.defocus_u = v3(c.defocus_disk_u); D.cam.defocus_v = v3(c.defocus_disk_v);
@@ -790,7 +812,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     sc->stack_entries = stack_entries;
     sc->lds_scene_bytes = (int)(((size_t)nodes * kNodeFields + (size_t)d->object_count * kPrimQuads) * 16 + xforms.size() * 4);
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
-    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + kWaves * kAccFloatsPerWave * 4 <= 40 * 1024;
+    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + (size_t)kWaves * kWaveLdsBytes <= 40 * 1024;
     sc->can_flat = can_flat;
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
