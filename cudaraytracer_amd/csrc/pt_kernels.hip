@@ -47,18 +47,10 @@ struct RenderArgs {
     FlatView flat;                   // small-scene box slots (flat mode)
     float* partial;                  // [chunks][14][pix_padded]  chunk sums, tile-major pixels
     unsigned long long* ray_counter;
+    unsigned int* queue;             // next work item (tile, chunk) to hand out; zero at launch
     int tiles_x, tiles_y, ntiles, pix_padded;
-    int first_sample, samples, chunk_size;
+    int first_sample, samples, chunk_size, chunks;
 };
-
-__device__ __forceinline__ int xcd_remap(int block, int nblocks) {
-    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
-    // so that neighbouring tiles (which walk the same BVH nodes) share one L2.  Bijective for
-    // any nblocks.
-    int q = nblocks >> 3, r = nblocks & 7, x = block & 7, k = block >> 3;
-    int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return start + k;
-}
 
 // Cooperative copy of the traversal data HBM -> LDS (field-major, see SceneLds).
 __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int nn, const float4* prims, int no,
@@ -104,11 +96,23 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
     acc_add(acc, plane, pix, v.x); acc_add(acc, plane + 1, pix, v.y); acc_add(acc, plane + 2, pix, v.z);
 }
 
-// LDS carve-up of a block: [pass sums: waves x 14 x 64 floats][stacks: STACK x 256 ints][scene copy]
-constexpr int kAccFloatsPerWave = kPasses * 64;
+// LDS carve-up of a block: [pass sums: waves x 2 x 14 x 64 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
+constexpr int kAccFloatsPerTile = kPasses * 64;
+constexpr int kAccFloatsPerWave = 2 * kAccFloatsPerTile;        // two work items in flight per wave
 constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
 constexpr int kWaveLdsBytes = (kAccFloatsPerWave + kCoopWordsPerWave) * 4;
 
+// One work item of a wave: the 8x8 pixel tile `tile`, samples [s0, s0 + items/64).
+struct WorkItem {
+    int tile, chunk, tx, ty, s0, next, total;
+    bool valid;
+};
+
+// The path tracer.  Persistent waves: the grid is sized to fill the chip once, and every wave
+// takes work items (an 8x8 tile x a chunk of samples) from a global counter until none are
+// left.  A wave keeps TWO items open: lanes whose path ended take new paths from the `fill`
+// item, while the last long paths of the previous item (`drain`) finish, so the wave stays
+// full across item boundaries; an item's tile sums go to HBM once its last path has ended.
 template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
     extern __shared__ float4 smem[];
@@ -119,11 +123,11 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     const DevScene& sc = A.sc;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* acc = acc_all + wave * kAccFloatsPerWave;              // [14][64] sums of this wave's tile
+    float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][64] sums of the wave's two open tiles
     volatile uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
     volatile float* coop_res = reinterpret_cast<volatile float*>(coop_pub + 128);
 #pragma unroll
-    for (int k = 0; k < kPasses; k++) acc[k * 64 + lane] = 0.0f;
+    for (int k = 0; k < 2 * kPasses; k++) acc[k * 64 + lane] = 0.0f;
 
     SceneGlobal SG;
     SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms;
@@ -133,25 +137,47 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x) * kWaves + wave;
-    if (tile >= A.ntiles) return;
-    const int tx = tile % A.tiles_x, ty = tile / A.tiles_x;
     LaneStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.stride = kBlock;
 
-    // Work pool of the wave: items (sample, pixel of the tile), sample-major.  A lane whose path
-    // ended takes the next item, whichever pixel it belongs to, so the wave stays full until the
-    // pool is empty; finished paths add their results to the tile's sums in LDS.
-    const int chunk = blockIdx.y;
-    const int s0 = A.first_sample + chunk * A.chunk_size;
-    const int s1 = min(s0 + A.chunk_size, A.first_sample + A.samples);
-    const int total_items = (s1 - s0) * 64;
-    int next_item = 0;                                            // wave-uniform
+    const int item_count = A.ntiles * A.chunks;
+    // next work item of this wave (wave-uniform); invalid once the counter has run past the end
+    auto fetch = [&]() {
+        WorkItem w;
+        unsigned int q = 0;
+        if (lane == 0) q = atomicAdd(A.queue, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        w.valid = q < (unsigned int)item_count;
+        w.chunk = (int)(q / (unsigned int)A.ntiles);
+        w.tile = (int)q - w.chunk * A.ntiles;
+        w.tx = w.tile % A.tiles_x; w.ty = w.tile / A.tiles_x;
+        w.s0 = A.first_sample + w.chunk * A.chunk_size;
+        const int s1 = min(w.s0 + A.chunk_size, A.first_sample + A.samples);
+        w.total = w.valid ? (s1 - w.s0) * 64 : 0;
+        w.next = 0;
+        return w;
+    };
+    // tile sums of one finished item -> HBM (lane = pixel of the tile), buffer cleared for the next item
+    auto flush = [&](int buffer, int tile, int chunk) {
+        float* sums = acc + buffer * kAccFloatsPerTile;
+        float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * 64 + lane;
+        const size_t ps = A.pix_padded;
+#pragma unroll
+        for (int k = 0; k < kPasses; k++) {
+            out[k * ps] = sums[k * 64 + lane];
+            sums[k * 64 + lane] = 0.0f;
+        }
+    };
+
+    WorkItem fill = fetch();                                      // wave-uniform state
+    int fill_buffer = 0;
+    bool draining = false;                                        // the other buffer holds an item whose paths are still running
+    int drain_tile = 0, drain_chunk = 0;
 
     unsigned int rays = 0;
     bool alive = false;
-    int pix = lane;                                               // pixel of the tile this lane's path belongs to
+    int pixoff = lane;                                            // buffer * 896 + pixel of the tile: where this lane's path adds its results
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
@@ -159,18 +185,39 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     Rng rng;
     rng.state = 0; rng.draws = 0;
 
+    SectionClock clk;
+    clk.start();
     while (true) {
         CRT_PROF(kProfOuter);
-        if (next_item < total_items) {                            // wave-uniform
+        CRT_CLOCK(clk, kSecRegen, ray.d.x);
+        // the drained item is complete when none of its paths is alive any more
+        if (draining) {
+            const int drain_base = (fill_buffer ^ 1) * kAccFloatsPerTile;
+            const bool mine = alive && ((pixoff >= kAccFloatsPerTile) == (drain_base != 0));
+            if (!__any(mine)) {
+                flush(fill_buffer ^ 1, drain_tile, drain_chunk);
+                draining = false;
+            }
+        }
+        // the fill item has handed out all its paths: let it drain and open the next one
+        if (fill.valid && fill.next >= fill.total && !draining) {
+            draining = true;
+            drain_tile = fill.tile; drain_chunk = fill.chunk;
+            fill_buffer ^= 1;
+            fill = fetch();
+        }
+        if (fill.next < fill.total) {                             // wave-uniform
             const unsigned long long free_mask = __ballot(!alive);
             if (!alive) {
                 CRT_PROF(kProfRegen);
-                const int item = next_item + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
-                if (item < total_items) {
-                    pix = item & 63;
-                    const int sample = s0 + (item >> 6) + 1;      // sample numbers are 1-based (render.cuh:128)
-                    const int pi = tx * 8 + (pix & 7), pj = ty * 8 + (pix >> 3);
+                CRT_MARK("regen");
+                const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
+                if (item < fill.total) {
+                    const int pix = item & 63;
+                    const int sample = fill.s0 + (item >> 6) + 1;  // sample numbers are 1-based (render.cuh:128)
+                    const int pi = fill.tx * 8 + (pix & 7), pj = fill.ty * 8 + (pix >> 3);
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
+                        pixoff = fill_buffer * kAccFloatsPerTile + pix;
                         rng.init(pj * sc.width + pi, sample);
                         ray = camera_ray(sc.cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
@@ -180,10 +227,12 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                     }
                 }
             }
-            next_item += __builtin_popcountll(free_mask);
+            fill.next += __builtin_popcountll(free_mask);
+            CRT_MARK("regen_done");
         }
+        CRT_CLOCK(clk, kSecOther, ray.o.x);
         if (!__any(alive)) {
-            if (next_item >= total_items) break;
+            if (!fill.valid && !draining) break;                  // queue empty and everything flushed
             continue;
         }
         Hit h;
@@ -194,11 +243,15 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         if (alive) {
             rays++;
             CRT_PROF(kProfTrace);
-            if constexpr (MODE == kModeFlat) h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY);
+            CRT_MARK("trace");
+            CRT_CLOCK(clk, MODE == kModeFlat ? kSecBox : kSecNode, ray.o.y);
+            if constexpr (MODE == kModeFlat) h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
             else if constexpr (MODE == kModeTreeLds) h = traverse(SL, ray, 0.001f, INFINITY, stk);
             else h = traverse(SG, ray, 0.001f, INFINITY, stk);    // render.cuh:47
+            CRT_CLOCK(clk, kSecSurface, h.t);
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
+                CRT_MARK("surface");
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
                 sf = make_surface(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
@@ -206,18 +259,23 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             }
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
+        CRT_MARK("coop");
+        CRT_CLOCK(clk, kSecSample, sf.p.x);
         const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
+        CRT_MARK("scatter");
+        V3 rv_dep = rv;
+        CRT_CLOCK(clk, kSecScatter, rv_dep.x);
         if (alive) {
             if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
-                if (scatter_with(sc, ray, sf, m0, rv, rng, attenuation, next)) {  // render.cuh:52-61
+                if (scatter_with(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         pend_albedo = attenuation;
                         V3 n = unit(sf.normal);
-                        acc_add3(acc, 9, pix, n);
-                        acc_add(acc, 12, pix, h.t * length(ray.d));
-                        acc_add(acc, 13, pix, 1.0f);
+                        acc_add3(acc, 9, pixoff, n);
+                        acc_add(acc, 12, pixoff, h.t * length(ray.d));
+                        acc_add(acc, 13, pixoff, 1.0f);
                     }
                     throughput = throughput * attenuation;
                     ray = next;
@@ -226,38 +284,35 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                 } else {                                             // render.cuh:64-74
                     V3 emitted = emit(sc, sf);
                     V3 c = throughput * emitted;
-                    acc_add3(acc, 0, pix, c);
+                    acc_add3(acc, 0, pixoff, c);
                     V3 alb = pend_albedo;
                     if (bounces == 0) {
                         alb = emitted;
                         V3 n = unit(sf.normal);
-                        acc_add3(acc, 6, pix, emitted);
-                        acc_add3(acc, 9, pix, n);
-                        acc_add(acc, 12, pix, h.t * length(ray.d));
-                        acc_add(acc, 13, pix, 1.0f);
+                        acc_add3(acc, 6, pixoff, emitted);
+                        acc_add3(acc, 9, pixoff, n);
+                        acc_add(acc, 12, pixoff, h.t * length(ray.d));
+                        acc_add(acc, 13, pixoff, 1.0f);
                     }
-                    acc_add3(acc, 3, pix, alb);
+                    acc_add3(acc, 3, pixoff, alb);
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment(sc, ray.d);
-                acc_add3(acc, 0, pix, c);
+                acc_add3(acc, 0, pixoff, c);
                 V3 alb = pend_albedo;
                 if (bounces == 0) {
                     alb = c;
-                    atomicAdd(&acc[12 * 64 + pix], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
+                    atomicAdd(&acc[12 * 64 + pixoff], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
                 }
-                acc_add3(acc, 3, pix, alb);
+                acc_add3(acc, 3, pixoff, alb);
                 alive = false;
             }
         }
+        CRT_MARK("iter_end");
+        CRT_CLOCK(clk, kSecOther, throughput.x);
     }
-
-    // tile sums -> HBM (lane = pixel of the tile); the wave's own LDS adds are complete here
-    float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * 64 + lane;
-    const size_t ps = A.pix_padded;
-#pragma unroll
-    for (int k = 0; k < kPasses; k++) out[k * ps] = acc[k * 64 + lane];
+    clk.flush();
 
     // one ray-count atomic per wave
     unsigned int total = rays;
@@ -327,7 +382,9 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     Ray ray = camera_ray(sc.cam, pi, pj, rng);
     Hit h;
     if constexpr (MODE == kModeFlat) {
-        h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY);
+        SectionClock clk;
+        clk.start();
+        h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
         if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
     } else {
         SceneGlobal S;
@@ -352,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
 using namespace crt;
 
 struct crt_scene {
-    int device = 0;
+    int device = 0, cu_count = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
     float last_trace_ms = 0.0f, last_resolve_ms = 0.0f;
@@ -744,6 +801,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
 
     crt_scene* sc = new crt_scene();
     if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; return crt::set_error(CRT_ERR_DEVICE, "crt_scene_create: no HIP device"); }
+    if (hipDeviceGetAttribute(&sc->cu_count, hipDeviceAttributeMultiprocessorCount, sc->device) != hipSuccess || sc->cu_count <= 0) sc->cu_count = 256;
 #define CRT_HIP_OR_FREE(call)                                                                                          \
     do {                                                                                                               \
         hipError_t e_ = (call);                                                                                        \
@@ -777,7 +835,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
-    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, sizeof(unsigned long long)));
+    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
 #undef CRT_HIP_OR_FREE
     uint8_t* base = static_cast<uint8_t*>(sc->blob);
     DevScene& D = sc->dev;
@@ -930,9 +988,15 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
         sc->partial_bytes = need;
     }
     A.partial = sc->partial;
+    A.chunks = chunks;
     A.ray_counter = sc->ray_counter;
-    CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, sizeof(unsigned long long), sc->stream));
-    dim3 grid((A.ntiles + (kBlock / 64) - 1) / (kBlock / 64), chunks);
+    A.queue = reinterpret_cast<unsigned int*>(sc->ray_counter + 1);
+    CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, 2 * sizeof(unsigned long long), sc->stream));
+    // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
+    const long long items = (long long)A.ntiles * chunks;
+    int resident = sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves);   // 4 SIMDs per CU
+    if (const char* e = std::getenv("CRT_BLOCKS")) resident = std::max(1, std::atoi(e));
+    dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
     int rc = launch_fused(sc, A, grid);
     if (rc != CRT_OK) return rc;
@@ -982,14 +1046,14 @@ int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms) {
     return CRT_OK;
 }
 
-int crt_profile_counters(uint64_t* out32, int reset) {
+int crt_profile_counters(uint64_t* out64, int reset) {
     crt::clear_error();
 #ifdef CRT_PROFILE
-    unsigned long long host[32];
-    if (out32) {
+    unsigned long long host[64];
+    if (out64) {
         CRT_HIP(hipDeviceSynchronize());
         CRT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(crt::g_prof), sizeof(host)));
-        for (int i = 0; i < 32; i++) out32[i] = host[i];
+        for (int i = 0; i < 64; i++) out64[i] = host[i];
     }
     if (reset) {
         std::memset(host, 0, sizeof(host));
@@ -997,7 +1061,7 @@ int crt_profile_counters(uint64_t* out32, int reset) {
     }
     return CRT_OK;
 #else
-    (void)out32; (void)reset;
+    (void)out64; (void)reset;
     return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_profile_counters: this library was built without -DCRT_PROFILE");
 #endif
 }

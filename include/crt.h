@@ -219,9 +219,10 @@ void* crt_scene_stream(crt_scene* sc);
 int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms);
 
 /* Development aid: loop-occupancy counters of a library built with -DCRT_PROFILE
- * (32 values: site k -> [2k] wave-level executions, [2k+1] active lanes).  The product build
- * returns CRT_ERR_UNSUPPORTED. */
-int crt_profile_counters(uint64_t* out32, int reset);
+ * (64 values: site k < 16 -> [2k] wave-level executions, [2k+1] active lanes; [32+s] shader
+ * clocks the waves spent in section s of the path loop).  The product build returns
+ * CRT_ERR_UNSUPPORTED. */
+int crt_profile_counters(uint64_t* out64, int reset);
 
 /* How the kernels reach the geometry: 0 = automatic (default), 1 = BVH4 walk with the scene in
  * HBM, 2 = BVH4 walk over an LDS copy of the scene (small scenes), 3 = flat box loop with a

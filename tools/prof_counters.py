@@ -13,7 +13,7 @@ buf = crt.create_buffer(sc)
 lib = crt.lib()
 assert lib.crt_profile_counters(None, 1) == 0, lib.crt_last_error()
 secs = crt.render(sc, buf)
-out = np.zeros(32, np.uint64)
+out = np.zeros(64, np.uint64)
 lib.crt_profile_counters(out.ctypes.data, 0)
 rays = api.last_ray_count
 names = ["outer", "regen", "trace", "node", "prim", "shade", "reject", "xform", "push"]
@@ -22,3 +22,10 @@ for k, n in enumerate(names):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
     if w:
         print(f"{n:8s} wave-execs {w:12d}  lanes {l:14d}  util {l / (64.0 * w):6.3f}  wave-execs/ray*64 {w * 64.0 / rays:7.3f}  lanes/ray {l / rays:7.3f}")
+secs_names = ["other", "regen", "box", "prim", "surface", "sample", "scatter", "node"]
+tot = float(sum(int(out[32 + k]) for k in range(8)))
+if tot:
+    print("wave clock share per section:")
+    for k, n in enumerate(secs_names):
+        print(f"  {n:8s} {int(out[32 + k]) / tot * 100:6.2f} %   raw {int(out[32 + k])}")
+    print(f"  total clocks {tot:.0f}, kernel {secs * 1e3:.2f} ms")
