@@ -74,6 +74,9 @@ IMAGE_LOADER = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_float, C.c_float, C.c_int, C
 # name -> (restype, argtypes); every symbol include/crt.h declares
 SIGNATURES = {
     "crt_set_image_loader": (C.c_int, [IMAGE_LOADER, C.c_void_p]),
+    "crt_load_image": (C.c_int, [C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]),
+    "crt_free": (None, [C.c_void_p]),
     "crt_scene_load_yaml": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "crt_scene_parse_yaml": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "crt_host_scene_set_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -60,9 +60,21 @@ def set_device(device):
 _loader_keepalive = None
 
 
+def load_image(filename, hdr_gamma=2.2, hdr_scale=1.0, desired_channels=0, flip_y=False):
+    """The image-file load of an image texture (texture.cuh:143-158) -> uint8 array [H, W, C]."""
+    w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+    px = C.POINTER(C.c_uint8)()
+    _check(_lib.crt_load_image(os.fsencode(filename), hdr_gamma, hdr_scale, desired_channels, 1 if flip_y else 0,
+                               C.byref(w), C.byref(h), C.byref(ch), C.byref(px)))
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, ch.value)).copy()
+    finally:
+        _lib.crt_free(px)
+
+
 def set_image_loader(fn):
     """Install a Python image decoder: fn(filename, gamma, scale, desired_channels, flip_y) ->
-    uint8 array [H, W, C].  Pass None to restore the built-in decoders (PNG, HDR, PPM)."""
+    uint8 array [H, W, C].  Pass None to restore the built-in decoders (PNG, JPEG, HDR, PNM)."""
     global _loader_keepalive
     if fn is None:
         _check(_lib.crt_set_image_loader(C.cast(None, _capi.IMAGE_LOADER), None))

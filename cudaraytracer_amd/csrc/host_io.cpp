@@ -76,46 +76,93 @@ bool decode_png(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::
         pos += 12 + len;
     }
     if (!have_ihdr || w <= 0 || h <= 0) { err = "bad PNG header"; return false; }
-    if (interlace != 0) { err = "interlaced PNG not supported"; return false; }
-    if (bit_depth != 8 && bit_depth != 16) { err = "PNG bit depth not supported"; return false; }
-    int src_ch = color_type == 0 ? 1 : color_type == 2 ? 3 : color_type == 3 ? 1 : color_type == 4 ? 2 : color_type == 6 ? 4 : 0;
-    if (!src_ch || (color_type == 3 && bit_depth != 8)) { err = "PNG colour type not supported"; return false; }
-    size_t bpp = (size_t)src_ch * bit_depth / 8, stride = (size_t)w * bpp;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    if (interlace > 1) { err = "bad PNG interlace method"; return false; }
+    if (bit_depth != 1 && bit_depth != 2 && bit_depth != 4 && bit_depth != 8 && bit_depth != 16) { err = "bad PNG bit depth"; return false; }
+    const int src_ch = color_type == 0 ? 1 : color_type == 2 ? 3 : color_type == 3 ? 1 : color_type == 4 ? 2 : color_type == 6 ? 4 : 0;
+    if (!src_ch || (color_type == 3 && bit_depth > 8) || (bit_depth < 8 && color_type != 0 && color_type != 3)) { err = "PNG colour type not supported"; return false; }
+    // inflate everything (the size is known: filter byte + packed row per scanline of each pass)
+    static const int px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int passes = interlace ? 7 : 1;
+    auto pass_dim = [&](int p, int& pw, int& ph) {
+        if (!interlace) { pw = w; ph = h; return; }
+        pw = (w - px0[p] + pdx[p] - 1) / pdx[p];
+        ph = (h - py0[p] + pdy[p] - 1) / pdy[p];
+    };
+    const size_t bits_pp = (size_t)src_ch * bit_depth;
+    size_t total = 0;
+    for (int p = 0; p < passes; p++) {
+        int pw, ph;
+        pass_dim(p, pw, ph);
+        if (pw > 0 && ph > 0) total += (((size_t)pw * bits_pp + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw(total);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) { err = "PNG inflate failed"; return false; }
-    std::vector<uint8_t> img(stride * h);
-    for (int y = 0; y < h; y++) {
-        const uint8_t* in = &raw[(stride + 1) * y];
-        uint8_t filter = in[0];
-        in++;
-        uint8_t* cur = &img[stride * y];
-        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-            int v = in[x];
-            switch (filter) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: err = "bad PNG filter"; return false;
+    // samples at full width: one uint16 per channel sample (palette indices and grey levels unscaled)
+    std::vector<uint16_t> samples((size_t)w * h * src_ch);
+    const size_t fbpp = bits_pp >= 8 ? bits_pp / 8 : 1;              // filter distance in bytes
+    size_t rpos = 0;
+    for (int p = 0; p < passes; p++) {
+        int pw, ph;
+        pass_dim(p, pw, ph);
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (int y = 0; y < ph; y++) {
+            const uint8_t filter = raw[rpos++];
+            const uint8_t* in = &raw[rpos];
+            rpos += stride;
+            for (size_t x = 0; x < stride; x++) {
+                int a = x >= fbpp ? cur[x - fbpp] : 0, b = prev[x], c = x >= fbpp ? prev[x - fbpp] : 0;
+                int v = in[x];
+                switch (filter) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: err = "bad PNG filter"; return false;
+                }
+                cur[x] = (uint8_t)v;
             }
-            cur[x] = (uint8_t)v;
+            const int oy = interlace ? py0[p] + y * pdy[p] : y;
+            for (int x = 0; x < pw; x++) {
+                const int ox = interlace ? px0[p] + x * pdx[p] : x;
+                uint16_t* dst = &samples[((size_t)oy * w + ox) * src_ch];
+                for (int k = 0; k < src_ch; k++) {
+                    const size_t idx = (size_t)x * src_ch + k;
+                    if (bit_depth == 16) dst[k] = (uint16_t)((cur[idx * 2] << 8) | cur[idx * 2 + 1]);
+                    else if (bit_depth == 8) dst[k] = cur[idx];
+                    else {
+                        const size_t bit = idx * bit_depth;
+                        dst[k] = (uint16_t)((cur[bit >> 3] >> (8 - bit_depth - (bit & 7))) & ((1 << bit_depth) - 1));
+                    }
+                }
+            }
+            prev.swap(cur);
         }
     }
-    // to 8 bit, expand palette
-    int out_ch = color_type == 3 ? (trns.empty() ? 3 : 4) : src_ch;
+    // to 8 bit: palette lookup, grey levels scaled to 0..255, high byte of 16-bit samples; a tRNS
+    // colour key adds an alpha channel (0 where the pixel equals the key)
+    const bool keyed = color_type != 3 && !trns.empty() && (color_type == 0 || color_type == 2) && trns.size() >= (size_t)src_ch * 2;
+    const int out_ch = color_type == 3 ? (trns.empty() ? 3 : 4) : src_ch + (keyed ? 1 : 0);
+    static const int grey_scale[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};
     out.resize((size_t)w * h * out_ch);
     for (size_t i = 0; i < (size_t)w * h; i++) {
+        const uint16_t* sp = &samples[i * src_ch];
+        uint8_t* o = &out[i * out_ch];
         if (color_type == 3) {
-            uint8_t idx = img[i];
-            for (int k = 0; k < 3; k++) out[i * out_ch + k] = (size_t)idx * 3 + k < palette.size() ? palette[idx * 3 + k] : 0;
-            if (out_ch == 4) out[i * 4 + 3] = idx < trns.size() ? trns[idx] : 255;
-        } else {
-            for (int k = 0; k < src_ch; k++) out[i * out_ch + k] = img[(i * src_ch + k) * (bit_depth / 8)];   // high byte of 16-bit
+            const size_t idx = sp[0];
+            for (int k = 0; k < 3; k++) o[k] = idx * 3 + k < palette.size() ? palette[idx * 3 + k] : 0;
+            if (out_ch == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
+            continue;
         }
+        bool is_key = keyed;
+        for (int k = 0; k < src_ch; k++) {
+            if (keyed && sp[k] != (uint16_t)((trns[2 * k] << 8) | trns[2 * k + 1])) is_key = false;
+            o[k] = bit_depth == 16 ? (uint8_t)(sp[k] >> 8) : bit_depth == 8 ? (uint8_t)sp[k] : (uint8_t)(sp[k] * grey_scale[bit_depth]);
+        }
+        if (keyed) o[src_ch] = is_key ? 0 : 255;
     }
     ch = out_ch;
     return true;
@@ -347,6 +394,9 @@ inline uint8_t color_value(float value) {
 
 namespace crt {
 
+bool decode_jpeg(const std::vector<uint8_t>& file, int req_comp, int& w, int& h, int& native, int& out_comp,
+                 std::vector<uint8_t>& out, std::string& err);   // jpeg_decode.cpp
+
 int set_error(int code, const std::string& message) {
     g_last_error = message;
     return code;
@@ -377,7 +427,15 @@ bool load_image_file(const std::string& path, float hdr_gamma, float hdr_scale, 
     std::vector<uint8_t> file;
     if (!read_file(path, file)) { error = "cannot read file"; return false; }
     bool ok;
-    if (ends_with_ci(path, ".png")) ok = decode_png(file, width, height, channels, pixels, error);
+    const bool is_jpeg = file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8;
+    if (is_jpeg) {
+        // like stb_image, a JPEG is converted to the requested channel count by its own decoder
+        // (a grey request on a YCbCr file returns the Y plane, not a luma of the RGB values)
+        int native = 0, got = 0;
+        ok = decode_jpeg(file, (desired_channels >= 1 && desired_channels <= 4) ? desired_channels : 0, width, height, native, got, pixels, error);
+        channels = got;
+    }
+    else if (ends_with_ci(path, ".png")) ok = decode_png(file, width, height, channels, pixels, error);
     else if (ends_with_ci(path, ".hdr")) ok = decode_hdr(file, hdr_gamma, hdr_scale, width, height, channels, pixels, error);
     else if (ends_with_ci(path, ".ppm") || ends_with_ci(path, ".pgm")) ok = decode_pnm(file, width, height, channels, pixels, error);
     else { error = "no built-in decoder for this file type (install one with crt_set_image_loader)"; return false; }
@@ -411,6 +469,22 @@ int crt_set_image_loader(crt_image_loader_fn fn, void* user) {
     g_loader_user = user;
     return CRT_OK;
 }
+
+int crt_load_image(const char* filename, float hdr_gamma, float hdr_scale, int desired_channels, int flip_y,
+                   int* width, int* height, int* channels, uint8_t** pixels) {
+    crt::clear_error();
+    if (!filename || !width || !height || !channels || !pixels) return crt::set_error(CRT_ERR_INVALID, "crt_load_image: null argument");
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!crt::load_image_file(filename, hdr_gamma, hdr_scale, desired_channels, flip_y != 0, *width, *height, *channels, px, err))
+        return crt::set_error(CRT_ERR_IO, std::string("crt_load_image: ") + filename + ": " + err);
+    *pixels = static_cast<uint8_t*>(std::malloc(px.size() ? px.size() : 1));
+    if (!*pixels) return crt::set_error(CRT_ERR_IO, "crt_load_image: out of memory");
+    std::memcpy(*pixels, px.data(), px.size());
+    return CRT_OK;
+}
+
+void crt_free(void* p) { std::free(p); }
 
 int crt_normalize_pass(int pass, int width, int height, float gamma, const float* data, uint8_t* out) {
     crt::clear_error();

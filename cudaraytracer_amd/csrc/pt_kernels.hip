@@ -968,10 +968,9 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     A.tiles_y = (sc->dev.height + 7) / 8;
     A.ntiles = A.tiles_x * A.tiles_y;
     A.pix_padded = A.ntiles * 64;
-    // Split the samples into chunks so that the grid has several times more waves than the
-    // chip holds (256 CUs x 16-32 waves); the tail of the launch then costs one chunk, not one
-    // whole pixel.
-    int target_waves = 65536;
+    // Work items: every 8x8 tile x a chunk of the samples.  About 32 items per resident wave keep
+    // the end of the launch (waves running dry one by one) to a few percent of its length.
+    int target_waves = 131072;
     if (const char* e = std::getenv("CRT_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
     int chunks = std::min(samples, std::max(1, (target_waves + A.ntiles - 1) / A.ntiles));
     A.chunk_size = (samples + chunks - 1) / chunks;

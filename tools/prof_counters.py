@@ -5,7 +5,6 @@ import numpy as np
 import cudaraytracer_amd as crt
 from cudaraytracer_amd import api
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
-crt.set_image_loader(crt.pillow_image_loader)
 sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name), base_dir=os.path.join(os.path.dirname(__file__), "..", "scenes"))
 if len(sys.argv) > 2:
     sc.set_render(samples=int(sys.argv[2]))

@@ -6,7 +6,6 @@ from cudaraytracer_amd import api
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-crt.set_image_loader(crt.pillow_image_loader)
 sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name), base_dir=os.path.join(os.path.dirname(__file__), "..", "scenes"))
 buf = crt.create_buffer(sc)
 for r in range(reps):
