@@ -396,6 +396,7 @@ namespace crt {
 
 bool decode_jpeg(const std::vector<uint8_t>& file, int req_comp, int& w, int& h, int& native, int& out_comp,
                  std::vector<uint8_t>& out, std::string& err);   // jpeg_decode.cpp
+bool write_jpeg(const char* filename, int w, int h, const uint8_t* rgb, int quality);   // jpeg_encode.cpp
 
 int set_error(int code, const std::string& message) {
     g_last_error = message;
@@ -520,6 +521,7 @@ int crt_write_image(const char* filename, const char* fmt, int width, int height
     std::string f = fmt;
     bool ok;
     if (f == "png") ok = write_png(filename, width, height, rgb);
+    else if (f == "jpg") ok = crt::write_jpeg(filename, width, height, rgb, 100);    // write_image's default quality (image.cuh:100)
     else if (f == "bmp") ok = write_bmp(filename, width, height, rgb);
     else if (f == "tga") ok = write_tga(filename, width, height, rgb);
     else if (f == "hdr") ok = write_hdr(filename, width, height, rgb);

@@ -74,3 +74,38 @@ def test_unsupported_format_is_an_error(crt, tmp_path):
     img = np.zeros((2, 2, 3), np.uint8)
     rc = crt.lib().crt_write_image(str(tmp_path / "x.gif").encode(), b"gif", 2, 2, img.ctypes.data)
     assert rc < 0 and b"Unsupported image format" in crt.lib().crt_last_error()
+
+
+def test_jpg_writer_round_trip_and_standard_tables(crt, tmp_path):
+    """-f jpg (write_jpg, image.cuh:42-44: quality 100).  The file must decode, with an
+    independent decoder and with our own, to the source pixels within the format's rounding,
+    and carry the typical Huffman tables of T.81 Annex K (compared with the copy Pillow writes)."""
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:37, 0:53]
+    img = np.stack([xx * 4 % 256, yy * 6 % 256, (xx + yy) * 3 % 256], -1).astype(np.uint8)
+    img[10:20, 10:30] = rng.integers(0, 256, (10, 20, 3), dtype=np.uint8)
+    img = np.ascontiguousarray(img)
+    path = str(tmp_path / "x.jpg")
+    assert crt.lib().crt_write_image(path.encode(), b"jpg", 53, 37, img.ctypes.data) == 0
+    back = np.asarray(Image.open(path).convert("RGB"), dtype=np.int32)
+    assert back.shape == img.shape
+    assert np.abs(back - img).max() <= 3 and np.abs(back - img).mean() <= 0.7
+    own = crt.load_image(path).astype(np.int32)
+    assert np.abs(own - img).max() <= 3
+
+    def dht_segments(data):
+        out, pos = {}, 2
+        while pos + 4 <= len(data) and data[pos] == 0xFF and data[pos + 1] != 0xDA:
+            length = (data[pos + 2] << 8) | data[pos + 3]
+            if data[pos + 1] == 0xC4:
+                body, k = data[pos + 4: pos + 2 + length], 0
+                while k < len(body):
+                    n = sum(body[k + 1: k + 17])
+                    out[body[k]] = bytes(body[k + 1: k + 17 + n])
+                    k += 17 + n
+            pos += 2 + length
+        return out
+
+    Image.fromarray(img).save(str(tmp_path / "pil.jpg"), quality=90, optimize=False)
+    ours, pils = dht_segments(open(path, "rb").read()), dht_segments(open(str(tmp_path / "pil.jpg"), "rb").read())
+    assert set(ours) == {0x00, 0x10, 0x01, 0x11} and ours == pils
