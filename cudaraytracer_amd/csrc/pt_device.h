@@ -100,7 +100,7 @@ enum { kProfOuter = 0, kProfRegen = 1, kProfTrace = 2, kProfNode = 3, kProfPrim 
        kProfXform = 7, kProfPush = 8 };
 
 constexpr float kPi = 3.1415926535897932385f;
-constexpr int kNodeFields = 7;        // minx miny minz maxx maxy maxz code   (float4 / int4 each)
+constexpr int kNodeFields = 8;        // minx miny minz maxx maxy maxz code order   (float4 / int4 each)
 constexpr int kNodeStrideGlobal = 8;  // float4 per node in HBM (one 128-byte line)
 constexpr int kPrimQuads = 3;         // float4 per primitive record
 constexpr int kShadeQuads = 6;        // float4 per shading record
@@ -129,6 +129,7 @@ struct DevScene {
     const DevImage* images;
     int32_t node_count, object_count, xform_count, material_count, texture_count, background_index;
     int32_t width, height, max_bounces;
+    int32_t root_entry;       // stack entry of BVH node 0: leafy flag in bit 0
     DevCamera cam;
 };
 
@@ -208,6 +209,7 @@ struct SceneGlobal {
     const float4* nodes;
     const float4* prims;
     const float* xforms;
+    int root_entry;        // stack entry of node 0
     __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[node * kNodeStrideGlobal + field]; }
     __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[obj * kPrimQuads + q]; }
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
@@ -217,17 +219,29 @@ struct SceneLds {
     const float4* prims;   // [3][object_count]
     const float* xforms;
     int node_count, object_count;
+    int root_entry;
     __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[field * node_count + node]; }
     __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[q * object_count + obj]; }
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
 };
 
-// Per-lane traversal stack: entry e of lane l lives at base[e * stride + l] (conflict-free).
+// Per-lane traversal stack.  The first kLdsStackMax entries of lane l live in LDS at
+// base[e * stride + l] (conflict-free); a walk that goes deeper continues in a per-thread slice
+// of global memory (spill[(e - lds_entries) * spill_stride]), so that LDS use - and with it the
+// number of resident waves - does not grow with the depth of the tree.
 struct LaneStack {
     int* base;
     int stride;
-    __device__ __forceinline__ void put(int e, int v) { base[e * stride] = v; }
-    __device__ __forceinline__ int get(int e) const { return base[e * stride]; }
+    int lds_entries;
+    int* spill;
+    size_t spill_stride;
+    __device__ __forceinline__ void put(int e, int v) {
+        if (e < lds_entries) base[e * stride] = v;
+        else spill[(size_t)(e - lds_entries) * spill_stride] = v;
+    }
+    __device__ __forceinline__ int get(int e) const {
+        return e < lds_entries ? base[e * stride] : spill[(size_t)(e - lds_entries) * spill_stride];
+    }
 };
 
 struct Hit {
@@ -279,98 +293,178 @@ __device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd
     return true;
 }
 
-template <class Mem>
-__device__ __forceinline__ bool prim_test(const Mem& S, int obj, const Ray& r, float tmin, float tmax, float& t, float& bu, float& bv) {
-    float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
-    int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
-    V3 o = r.o, d = r.d;
-    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(S.xform(xf), r.o, r.d, o, d); }
-    if (type == 2) return tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, tmax, t, bu, bv);
-    bu = 0.0f; bv = 0.0f;
-    return sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, t);
+// Order-independent form of "if (hit(r, [tmin, closest])) closest = rec.t" (bvh.cuh:407-411).
+// The closest hit does not depend on the order of the tests except when two candidates have
+// exactly the same t.  The reference visits leaf slots in a fixed depth-first order that does
+// not depend on the ray (bvh.cuh:387-419: slots 0..3 in order, children popped last-in
+// first-out), accepts a triangle on the closed interval (hittable.cuh:335) and a sphere on the
+// open one (:287-289).  With `rank` = position of a primitive in that order, "tested later wins
+// a tie if it is a triangle, never if it is a sphere" reproduces the reference's choice in any
+// test order.  best.obj holds the rank of the best candidate so far.
+__device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, float t, int rank, bool is_tri, float bu, float bv) {
+    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? is_tri : !best_tri);
+    if (ok && (t < best.t || (t == best.t && win_tie))) {
+        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_tri = is_tri;
+    }
 }
 
-// Closest hit over the flat BVH4.
+// Closest hit over the flat BVH4, resumable.
 //
-// Order of evaluation per ray follows bvh.cuh:387-419: the four slots of a node in storage
-// order, a leaf slot's primitive tested before later slots are considered (so a later slot
-// sees the shrunken interval), internal children pushed in slot order and popped last-in
-// first-out.  Candidates with exactly equal t therefore resolve to the same object as in the
-// reference.  (In a node that mixes leaf and internal slots the internal children are pushed
-// on the interval at node entry, a superset of what the reference pushes; its own builder
-// never produces such nodes.)
+// The walk differs from bvh.cuh:387-419 in the ORDER nodes are visited (children nearest along
+// the ray first, from a per-node table indexed by the ray's direction octant) and gives the
+// same hit: the tie rule of consider() makes the result independent of the order, and a box is
+// only skipped when it lies entirely beyond the closest hit so far (hi < lo exactly as in
+// aabb.cuh:139-154, with the interval's upper end at the current closest t).
 //
 // For the wave the work is split into two alternating phases ("while-while"):
 //   node phase  every lane that has no pending primitives descends (box tests, pushes, pop)
 //               until it reaches a node with leaf candidates or runs out of nodes;
 //   prim phase  every lane tests its pending candidates, one per round, in slot order.
 // Lanes reach leaves at different times; testing primitives the moment one lane finds them
-// would run the long intersection code for a handful of lanes (measured: 8 % of the lanes
-// active), while batching them keeps both phases mostly full.
-template <class Mem>
-__device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, float tmax, LaneStack stk) {
-    // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
-    float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;
-    float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
-    float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
-    // field numbers of the near / far planes per axis (swap when the reciprocal is negative)
-    int nx = ix < 0.0f ? 3 : 0, fx = 3 - nx;
-    int ny = iy < 0.0f ? 4 : 1, fy = 5 - ny;
-    int nz = iz < 0.0f ? 5 : 2, fz = 7 - nz;
+// would run the long intersection code for a handful of lanes, while batching them keeps both
+// phases fuller.
+//
+// Rays need very different numbers of steps, so a wave that waits for its slowest ray runs
+// mostly empty.  tree_run() therefore returns as soon as fewer than `min_active` lanes are
+// still walking; the caller shades the finished lanes, gives them new rays and calls again,
+// and the unfinished lanes simply continue from their saved state (registers + LDS stack).
+struct TreeState {
+    int node, sp;                       // next node to visit as a stack entry: index*2 + leafy (-1: none left), stack height
+    unsigned leaf_mask;                 // pending leaf slots of the last visited node
+    int c0, c1, c2, c3;                 // its slot codes
+    float l0, l1, l2, l3;               // and box entry distances
+    Hit best;                           // best.obj = visiting rank while walking
+    int best_obj;                       // object index of the best candidate
+    bool best_tri;
+    __device__ __forceinline__ void begin(float tmax, int root_entry) {
+        node = root_entry; sp = 0; leaf_mask = 0;
+        c0 = c1 = c2 = c3 = -1;
+        l0 = l1 = l2 = l3 = 0.0f;
+        best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
+        best_obj = -1; best_tri = false;
+    }
+    __device__ __forceinline__ Hit result() const { Hit h = best; h.obj = best_obj; return h; }
+};
 
-    Hit best;
-    best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
-    int sp = 0;
-    int node = 0;                       // next node to visit, -1 when the stack ran empty
-    unsigned leaf_mask = 0;             // pending leaf slots of the last visited node
-    int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
-    float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
-    while (true) {
-        while (node >= 0 && leaf_mask == 0) {                       // ---- node phase
+template <class Mem>
+__device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, float tmin, TreeState& ts) {
+    float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
+    const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
+    V3 o = r.o, d = r.d;
+    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(S.xform(xf), r.o, r.d, o, d); }
+    const int before = ts.best.obj;
+    if (type == 2) {
+        float t = 0.0f, bu = 0.0f, bv = 0.0f;
+        const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, t, bu, bv);
+        consider(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
+    } else {
+        // the root the reference would take does not depend on the interval's upper end: the
+        // near root if it is beyond tmin, else the far one (hittable.cuh:283-289)
+        float t = 0.0f;
+        const bool ok = sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, INFINITY, t);
+        consider(ts.best, ts.best_tri, ok, t, rank, false, 0.0f, 0.0f);
+    }
+    if (ts.best.obj != before) ts.best_obj = obj;
+}
+
+// One wave-wide loop; in every round
+//   * each lane that can takes ONE node step (box tests of the four slots, pushes, pop).  A lane
+//     that already holds untested leaf candidates keeps descending through internal nodes and
+//     only stops in front of the next node that has leaf slots ("leafy": flagged in the
+//     reference to it, bit 0 of a stack entry);
+//   * leaf candidates are tested, one per lane, once at least `prim_batch` lanes hold some (or
+//     nobody can take a node step): the long intersection code then runs for a batch of lanes
+//     instead of the one or two that happen to reach a leaf in a given round.
+template <class Mem>
+__device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin, TreeState& ts, bool& walking, LaneStack stk, int min_active, int prim_batch) {
+    // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
+    const float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;
+    const float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
+    const float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
+    // field numbers of the near / far planes per axis (swap when the reciprocal is negative)
+    const int nx = ix < 0.0f ? 3 : 0, fx = 3 - nx;
+    const int ny = iy < 0.0f ? 4 : 1, fy = 5 - ny;
+    const int nz = iz < 0.0f ? 5 : 2, fz = 7 - nz;
+    const int octant = (ix < 0.0f ? 1 : 0) | (iy < 0.0f ? 2 : 0) | (iz < 0.0f ? 4 : 0);
+
+    while (true) {                                                  // wave-uniform
+        const bool node_step = walking && ts.node >= 0 && !((ts.node & 1) && ts.leaf_mask);
+        if (node_step) {
             CRT_PROF(kProfNode);
+            const int node = ts.node >> 1;
             float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
             float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
             float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
-            float4 codef = S.node_field(node, 6);
+            float4 codef = S.node_field(node, 6), orderf = S.node_field(node, 7);
             const float nxs[4] = {bnx.x, bnx.y, bnx.z, bnx.w}, fxs[4] = {bfx.x, bfx.y, bfx.z, bfx.w};
             const float nys[4] = {bny.x, bny.y, bny.z, bny.w}, fys[4] = {bfy.x, bfy.y, bfy.z, bfy.w};
             const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
             const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
             float los[4];
+            unsigned push_mask = 0, leaf_hits = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
-                float lo = fmaxf(tmin, t0), hi = fminf(best.t, t1);
+                float lo = fmaxf(tmin, t0), hi = fminf(ts.best.t, t1);
                 t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
                 lo = fmaxf(lo, t0); hi = fminf(hi, t1);
                 t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
                 lo = fmaxf(lo, t0); hi = fminf(hi, t1);
                 los[i] = lo;
                 if (!(hi < lo)) {
-                    if (codes[i] >= 0) leaf_mask |= 1u << i;
-                    else if (codes[i] < -1) stk.put(sp++, -codes[i] - 2);
+                    if (codes[i] >= 0) leaf_hits |= 1u << i;
+                    else if (codes[i] < -1) push_mask |= 1u << i;
                 }
             }
-            c0 = codes[0]; c1 = codes[1]; c2 = codes[2]; c3 = codes[3];
-            l0 = los[0]; l1 = los[1]; l2 = los[2]; l3 = los[3];
-            if (leaf_mask == 0) node = sp ? stk.get(--sp) : -1;
+            // internal children: farthest first, so that the nearest is popped first
+            if (push_mask) {
+                const unsigned word = (unsigned)__float_as_int(octant < 4 ? orderf.x : orderf.y);
+                const unsigned order = (word >> ((octant & 3) * 8)) & 0xffu;      // 4 x 2 bits, near to far
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const unsigned slot = (order >> (2 * k)) & 3u;
+                    if ((push_mask >> slot) & 1u) {
+                        const int code = slot == 0 ? codes[0] : (slot == 1 ? codes[1] : (slot == 2 ? codes[2] : codes[3]));
+                        stk.put(ts.sp++, -code - 2);
+                    }
+                }
+            }
+            if (leaf_hits) {                                        // only reached with no candidates pending
+                ts.leaf_mask = leaf_hits;
+                ts.c0 = codes[0]; ts.c1 = codes[1]; ts.c2 = codes[2]; ts.c3 = codes[3];
+                ts.l0 = los[0]; ts.l1 = los[1]; ts.l2 = los[2]; ts.l3 = los[3];
+            }
+            ts.node = ts.sp ? stk.get(--ts.sp) : -1;
         }
-        if (leaf_mask == 0) break;                                  // no node left and nothing pending
-        while (leaf_mask) {                                         // ---- prim phase
-            const int i = __builtin_ctz(leaf_mask);
-            leaf_mask &= leaf_mask - 1;
-            const int code = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3));
-            const float lo = i == 0 ? l0 : (i == 1 ? l1 : (i == 2 ? l2 : l3));
-            // an earlier slot of this node may have shrunk the interval below this box's entry:
-            // the reference's slab test (run after that hit) would reject the slot
-            if (best.t < lo) continue;
-            CRT_PROF(kProfPrim);
-            float t, bu, bv;
-            if (prim_test(S, code, r, tmin, best.t, t, bu, bv)) { best.t = t; best.obj = code; best.bu = bu; best.bv = bv; }
+        const bool has_prim = walking && ts.leaf_mask != 0;
+        const int pending = __builtin_popcountll(__ballot(has_prim));
+        const bool more_nodes = __any(walking && ts.node >= 0 && !((ts.node & 1) && ts.leaf_mask));
+        if (pending && (pending >= prim_batch || !more_nodes)) {
+            if (has_prim) {
+                const int i = __builtin_ctz(ts.leaf_mask);
+                ts.leaf_mask &= ts.leaf_mask - 1;
+                const int code = i == 0 ? ts.c0 : (i == 1 ? ts.c1 : (i == 2 ? ts.c2 : ts.c3));
+                const float lo = i == 0 ? ts.l0 : (i == 1 ? ts.l1 : (i == 2 ? ts.l2 : ts.l3));
+                // an earlier candidate may have shrunk the interval below this box's entry
+                if (!(ts.best.t < lo)) {
+                    CRT_PROF(kProfPrim);
+                    tree_prim(S, code, r, tmin, ts);
+                }
+            }
         }
-        node = sp ? stk.get(--sp) : -1;
+        if (walking && ts.node < 0 && ts.leaf_mask == 0) walking = false;
+        if (__builtin_popcountll(__ballot(walking)) < min_active) break;
     }
-    return best;
+}
+
+// One whole walk (used where no lane is refilled in between).
+template <class Mem>
+__device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, float tmax, LaneStack stk) {
+    TreeState ts;
+    ts.begin(tmax, S.root_entry);
+    bool walking = true;
+    tree_run(S, r, tmin, ts, walking, stk, 1, 16);
+    return ts.result();
 }
 
 // ------------------------------------------------------------------ flat traversal ------
@@ -474,14 +568,6 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
     r.t = dot(e2, qvec) * inv_det;
     r.ok = ok && (tmin <= r.t && r.t <= tmax);
     return r;
-}
-
-// Order-independent form of "if (hit(r, [tmin, closest])) closest = rec.t" (bvh.cuh:407-411).
-__device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, float t, int rank, bool is_tri, float bu, float bv) {
-    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? is_tri : !best_tri);
-    if (ok && (t < best.t || (t == best.t && win_tie))) {
-        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_tri = is_tri;
-    }
 }
 
 template <int GROUPS>

@@ -3,14 +3,15 @@
 // Replaces render() / render_kernel (src/render.cuh:108-181) and the per-element scene
 // upload of scene::scene (src/scene.cuh:61-89).
 //
-// Kernel structure (fused mode, the default)
-//   render_fused   one lane owns one pixel of an 8x8 tile and walks the samples of its chunk.
-//                  Path regeneration keeps the wave full: a lane whose path ended starts its
-//                  next sample in the same iteration in which the other lanes trace their next
-//                  bounce, so divergence over path LENGTH (1..max_bounces) never idles lanes;
-//                  the only divergence left is inside one traversal / one shading step.
-//                  Sums of the six passes stay in registers; nothing but the final 14 floats
-//                  per (pixel, chunk) touches HBM.
+// Kernel structure
+//   render_fused   persistent waves.  A wave takes work items (an 8x4 pixel tile x a chunk of the
+//                  samples) from a global counter; every lane carries one path.  A lane whose
+//                  path ended starts the next path of the item in the same iteration in which
+//                  the other lanes trace their next bounce, so divergence over path LENGTH
+//                  (1..max_bounces) never idles lanes, and two items are open at a time so the
+//                  last long paths of one item overlap the first paths of the next.  Finished
+//                  paths add their results to the item's tile sums in LDS; one store of
+//                  14 floats per (pixel, chunk) is all that reaches HBM.
 //   resolve_passes adds the chunk sums in chunk order, folds them into the running mean of
 //                  the pass buffers ((old*done + sum) / (done + n), which for n = 1 is the
 //                  reference's update at render.cuh:147-152) and writes the reference layout.
@@ -31,9 +32,14 @@ namespace crt {
 #ifndef CRT_FUSED_WAVES_PER_SIMD
 #define CRT_FUSED_WAVES_PER_SIMD 4    // register budget of render_fused: 512 / 4 = 128 VGPRs
 #endif
-constexpr int kBlock = 256;          // 4 waves; one 8x8 pixel tile per wave
+constexpr int kBlock = 256;          // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
+// Pixels of one work item: 8 wide, 8 rows in flat mode (one sample of every pixel fills a wave:
+// lanes that finish together add to different LDS words) and 4 rows in the tree modes (half the
+// LDS per wave, which there buys a fourth resident block per CU next to the traversal stacks).
+constexpr int kTileW = 8;
+constexpr int tile_rows(int mode) { return mode == 2 ? 8 : 4; }
 
 // How a kernel reaches the scene geometry
 enum : int {
@@ -47,9 +53,13 @@ struct RenderArgs {
     FlatView flat;                   // small-scene box slots (flat mode)
     float* partial;                  // [chunks][14][pix_padded]  chunk sums, tile-major pixels
     unsigned long long* ray_counter;
+    int* stack_spill;                // tree modes: global part of the traversal stacks, [entries][spill_threads]
+    int spill_threads;
     unsigned int* queue;             // next work item (tile, chunk) to hand out; zero at launch
     int tiles_x, tiles_y, ntiles, pix_padded;
     int first_sample, samples, chunk_size, chunks;
+    int prim_batch;                  // tree modes: lanes with leaf candidates that trigger a round of primitive tests
+    int ready_percent;               // tree modes: shade once this share of the wave's rays has finished its walk
 };
 
 // Cooperative copy of the traversal data HBM -> LDS (field-major, see SceneLds).
@@ -68,7 +78,7 @@ __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int 
     }
     for (int i = threadIdx.x; i < nx * kXformFloats; i += kBlock) lx[i] = xforms[i];
     SceneLds m;
-    m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no;
+    m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no; m.root_entry = 0;
     return m;
 }
 
@@ -89,32 +99,35 @@ __device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const fl
 // Adds a finished path's contribution to the tile sums.  Adding an exact zero cannot change a
 // sum (sums start at +0 and x + 0 == x for every x including NaN), so zeros are skipped: most
 // contributions of short paths are zero (black environment, non-emitting first hit).
+template <int TP>
 __device__ __forceinline__ void acc_add(float* acc, int plane, int pix, float v) {
-    if (v != 0.0f) atomicAdd(&acc[plane * 64 + pix], v);
+    if (v != 0.0f) atomicAdd(&acc[plane * TP + pix], v);
 }
+template <int TP>
 __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
-    acc_add(acc, plane, pix, v.x); acc_add(acc, plane + 1, pix, v.y); acc_add(acc, plane + 2, pix, v.z);
+    acc_add<TP>(acc, plane, pix, v.x); acc_add<TP>(acc, plane + 1, pix, v.y); acc_add<TP>(acc, plane + 2, pix, v.z);
 }
 
-// LDS carve-up of a block: [pass sums: waves x 2 x 14 x 64 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
-constexpr int kAccFloatsPerTile = kPasses * 64;
-constexpr int kAccFloatsPerWave = 2 * kAccFloatsPerTile;        // two work items in flight per wave
+// LDS carve-up of a block: [pass sums: waves x 2 x 14 x 32 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
 constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
-constexpr int kWaveLdsBytes = (kAccFloatsPerWave + kCoopWordsPerWave) * 4;
+constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
+constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave) * 4; }
 
-// One work item of a wave: the 8x8 pixel tile `tile`, samples [s0, s0 + items/64).
+// One work item of a wave: the 8x4 pixel tile `tile`, samples [s0, s0 + items/32).
 struct WorkItem {
     int tile, chunk, tx, ty, s0, next, total;
     bool valid;
 };
 
 // The path tracer.  Persistent waves: the grid is sized to fill the chip once, and every wave
-// takes work items (an 8x8 tile x a chunk of samples) from a global counter until none are
+// takes work items (an 8x4 pixel tile x a chunk of samples) from a global counter until none are
 // left.  A wave keeps TWO items open: lanes whose path ended take new paths from the `fill`
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
 template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
+    constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
+    constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
     extern __shared__ float4 smem[];
     float* acc_all = reinterpret_cast<float*>(smem);
     uint32_t* coop_all = reinterpret_cast<uint32_t*>(acc_all + kWaves * kAccFloatsPerWave);
@@ -123,16 +136,16 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     const DevScene& sc = A.sc;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][64] sums of the wave's two open tiles
+    float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][tile pixels] sums of the wave's two open tiles
     volatile uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
     volatile float* coop_res = reinterpret_cast<volatile float*>(coop_pub + 128);
 #pragma unroll
-    for (int k = 0; k < 2 * kPasses; k++) acc[k * 64 + lane] = 0.0f;
+    for (int k = 0; k < kAccFloatsPerWave / 64; k++) acc[k * 64 + lane] = 0.0f;
 
     SceneGlobal SG;
-    SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms;
+    SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms; SG.root_entry = sc.root_entry;
     SceneLds SL = {};
-    if constexpr (MODE == kModeTreeLds) SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene);
+    if constexpr (MODE == kModeTreeLds) { SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene); SL.root_entry = sc.root_entry; }
     FlatLds FL = {};
     if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
@@ -140,6 +153,9 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     LaneStack stk;
     stk.base = stack_mem + threadIdx.x;
     stk.stride = kBlock;
+    stk.lds_entries = STACK;
+    stk.spill = A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    stk.spill_stride = (size_t)A.spill_threads;
 
     const int item_count = A.ntiles * A.chunks;
     // next work item of this wave (wave-uniform); invalid once the counter has run past the end
@@ -154,19 +170,21 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         w.tx = w.tile % A.tiles_x; w.ty = w.tile / A.tiles_x;
         w.s0 = A.first_sample + w.chunk * A.chunk_size;
         const int s1 = min(w.s0 + A.chunk_size, A.first_sample + A.samples);
-        w.total = w.valid ? (s1 - w.s0) * 64 : 0;
+        w.total = w.valid ? (s1 - w.s0) * kTilePixels : 0;
         w.next = 0;
         return w;
     };
     // tile sums of one finished item -> HBM (lane = pixel of the tile), buffer cleared for the next item
     auto flush = [&](int buffer, int tile, int chunk) {
         float* sums = acc + buffer * kAccFloatsPerTile;
-        float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * 64 + lane;
+        float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * kTilePixels + lane;
         const size_t ps = A.pix_padded;
+        if (lane < kTilePixels) {
 #pragma unroll
-        for (int k = 0; k < kPasses; k++) {
-            out[k * ps] = sums[k * 64 + lane];
-            sums[k * 64 + lane] = 0.0f;
+            for (int k = 0; k < kPasses; k++) {
+                out[k * ps] = sums[k * kTilePixels + lane];
+                sums[k * kTilePixels + lane] = 0.0f;
+            }
         }
     };
 
@@ -177,13 +195,16 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
 
     unsigned int rays = 0;
     bool alive = false;
-    int pixoff = lane;                                            // buffer * 896 + pixel of the tile: where this lane's path adds its results
+    int pixoff = 0;                                               // buffer * 448 + pixel of the tile: where this lane's path adds its results
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
     int bounces = 0;
     Rng rng;
     rng.state = 0; rng.draws = 0;
+    TreeState ts;                                                 // tree modes: the lane's walk in progress
+    ts.begin(INFINITY, sc.root_entry);
+    bool walking = false;
 
     SectionClock clk;
     clk.start();
@@ -213,9 +234,9 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                 CRT_MARK("regen");
                 const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
                 if (item < fill.total) {
-                    const int pix = item & 63;
-                    const int sample = fill.s0 + (item >> 6) + 1;  // sample numbers are 1-based (render.cuh:128)
-                    const int pi = fill.tx * 8 + (pix & 7), pj = fill.ty * 8 + (pix >> 3);
+                    const int pix = item & (kTilePixels - 1);
+                    const int sample = fill.s0 + item / kTilePixels + 1;  // sample numbers are 1-based (render.cuh:128)
+                    const int pi = fill.tx * kTileW + (pix & 7), pj = fill.ty * kTileH + (pix >> 3);
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
                         pixoff = fill_buffer * kAccFloatsPerTile + pix;
                         rng.init(pj * sc.width + pi, sample);
@@ -224,6 +245,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                         pend_albedo = v3(0, 0, 0);
                         bounces = 0;
                         alive = true;
+                        if constexpr (MODE != kModeFlat) { ts.begin(INFINITY, sc.root_entry); walking = true; }
                     }
                 }
             }
@@ -240,14 +262,27 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         Surface sf = {};
         float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int mat_type = -1;
-        if (alive) {
+        // closest hit (render.cuh:47).  Flat mode: every living lane, in one go.  Tree modes: the
+        // walks run until enough of them have finished; only those lanes are shaded this time.
+        bool ready = alive;
+        if constexpr (MODE != kModeFlat) {
+            CRT_CLOCK(clk, kSecNode, ray.o.y);
+            const int living = __builtin_popcountll(__ballot(alive));
+            const int ready_target = max(1, living * A.ready_percent / 100);
+            if constexpr (MODE == kModeTreeLds) tree_run(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            else tree_run(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            ready = alive && !walking;
+        }
+        if (ready) {
             rays++;
             CRT_PROF(kProfTrace);
             CRT_MARK("trace");
-            CRT_CLOCK(clk, MODE == kModeFlat ? kSecBox : kSecNode, ray.o.y);
-            if constexpr (MODE == kModeFlat) h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
-            else if constexpr (MODE == kModeTreeLds) h = traverse(SL, ray, 0.001f, INFINITY, stk);
-            else h = traverse(SG, ray, 0.001f, INFINITY, stk);    // render.cuh:47
+            if constexpr (MODE == kModeFlat) {
+                CRT_CLOCK(clk, kSecBox, ray.o.y);
+                h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+            } else {
+                h = ts.result();
+            }
             CRT_CLOCK(clk, kSecSurface, h.t);
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         CRT_MARK("scatter");
         V3 rv_dep = rv;
         CRT_CLOCK(clk, kSecScatter, rv_dep.x);
-        if (alive) {
+        if (ready) {
             if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
@@ -273,39 +308,40 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                     if (bounces == 0) {
                         pend_albedo = attenuation;
                         V3 n = unit(sf.normal);
-                        acc_add3(acc, 9, pixoff, n);
-                        acc_add(acc, 12, pixoff, h.t * length(ray.d));
-                        acc_add(acc, 13, pixoff, 1.0f);
+                        acc_add3<kTilePixels>(acc, 9, pixoff, n);
+                        acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
+                        acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
                     }
                     throughput = throughput * attenuation;
                     ray = next;
                     bounces++;
                     if (bounces >= sc.max_bounces) alive = false;   // exhausted: col = albedo = 0 (render.cuh:96-97)
+                    else if constexpr (MODE != kModeFlat) { ts.begin(INFINITY, sc.root_entry); walking = true; }
                 } else {                                             // render.cuh:64-74
                     V3 emitted = emit(sc, sf);
                     V3 c = throughput * emitted;
-                    acc_add3(acc, 0, pixoff, c);
+                    acc_add3<kTilePixels>(acc, 0, pixoff, c);
                     V3 alb = pend_albedo;
                     if (bounces == 0) {
                         alb = emitted;
                         V3 n = unit(sf.normal);
-                        acc_add3(acc, 6, pixoff, emitted);
-                        acc_add3(acc, 9, pixoff, n);
-                        acc_add(acc, 12, pixoff, h.t * length(ray.d));
-                        acc_add(acc, 13, pixoff, 1.0f);
+                        acc_add3<kTilePixels>(acc, 6, pixoff, emitted);
+                        acc_add3<kTilePixels>(acc, 9, pixoff, n);
+                        acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
+                        acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
                     }
-                    acc_add3(acc, 3, pixoff, alb);
+                    acc_add3<kTilePixels>(acc, 3, pixoff, alb);
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment(sc, ray.d);
-                acc_add3(acc, 0, pixoff, c);
+                acc_add3<kTilePixels>(acc, 0, pixoff, c);
                 V3 alb = pend_albedo;
                 if (bounces == 0) {
                     alb = c;
-                    atomicAdd(&acc[12 * 64 + pixoff], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
+                    atomicAdd(&acc[12 * kTilePixels + pixoff], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
                 }
-                acc_add3(acc, 3, pixoff, alb);
+                acc_add3<kTilePixels>(acc, 3, pixoff, alb);
                 alive = false;
             }
         }
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
 struct ResolveArgs {
     const float* partial;
     float *color, *albedo, *emission, *normal, *depth, *opacity;
-    int width, height, tiles_x, ntiles, pix_padded, chunks;
+    int width, height, tiles_x, tile_rows, ntiles, pix_padded, chunks;
     float done, count;     // samples already in the buffers / samples summed now
     int fold;              // 0: overwrite with sum/count, 1: (old*done + sum)/(done+count)
 };
@@ -332,8 +368,9 @@ struct ResolveArgs {
 __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= R.pix_padded) return;
-    const int tile = t >> 6, lane = t & 63;
-    const int pi = (tile % R.tiles_x) * 8 + (lane & 7), pj = (tile / R.tiles_x) * 8 + (lane >> 3);
+    const int tile_pixels = kTileW * R.tile_rows;
+    const int tile = t / tile_pixels, lane = t - tile * tile_pixels;
+    const int pi = (tile % R.tiles_x) * kTileW + (lane & 7), pj = (tile / R.tiles_x) * R.tile_rows + (lane >> 3);
     if (pi >= R.width || pj >= R.height) return;
     const int pixel = pj * R.width + pi;
     float v[kPasses];
@@ -364,6 +401,8 @@ struct PrimaryArgs {
     int32_t* obj;
     float *t, *u, *v;
     int32_t* front;
+    int* stack_spill;
+    int spill_threads;
 };
 template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
@@ -374,32 +413,36 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     FlatLds FL = {};
     if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= sc.width * sc.height) return;
-    const int pi = idx % sc.width, pj = idx / sc.width;
-    Rng rng;
-    rng.init(idx, A.sample);
-    Ray ray = camera_ray(sc.cam, pi, pj, rng);
-    Hit h;
-    if constexpr (MODE == kModeFlat) {
-        SectionClock clk;
-        clk.start();
-        h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
-        if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
-    } else {
-        SceneGlobal S;
-        S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms;
-        LaneStack stk;
-        stk.base = stack_mem + threadIdx.x;
-        stk.stride = kBlock;
-        h = traverse(S, ray, 0.001f, INFINITY, stk);
-    }
-    A.obj[idx] = h.obj;
-    if (h.obj >= 0) {
-        Surface sf = make_surface(sc, ray, h);
-        A.t[idx] = h.t; A.u[idx] = sf.u; A.v[idx] = sf.v; A.front[idx] = sf.front ? 1 : 0;
-    } else {
-        A.t[idx] = INFINITY; A.u[idx] = 0.0f; A.v[idx] = 0.0f; A.front[idx] = 0;
+    // grid-stride over the pixels: the grid is bounded so that the stacks' global part is too
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < sc.width * sc.height; idx += gridDim.x * kBlock) {
+        const int pi = idx % sc.width, pj = idx / sc.width;
+        Rng rng;
+        rng.init(idx, A.sample);
+        Ray ray = camera_ray(sc.cam, pi, pj, rng);
+        Hit h;
+        if constexpr (MODE == kModeFlat) {
+            SectionClock clk;
+            clk.start();
+            h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+            if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
+        } else {
+            SceneGlobal S;
+            S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+            LaneStack stk;
+            stk.base = stack_mem + threadIdx.x;
+            stk.stride = kBlock;
+            stk.lds_entries = STACK;
+            stk.spill = A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+            stk.spill_stride = (size_t)A.spill_threads;
+            h = traverse(S, ray, 0.001f, INFINITY, stk);
+        }
+        A.obj[idx] = h.obj;
+        if (h.obj >= 0) {
+            Surface sf = make_surface(sc, ray, h);
+            A.t[idx] = h.t; A.u[idx] = sf.u; A.v[idx] = sf.v; A.front[idx] = sf.front ? 1 : 0;
+        } else {
+            A.t[idx] = INFINITY; A.u[idx] = 0.0f; A.v[idx] = 0.0f; A.front[idx] = 0;
+        }
     }
 }
 
@@ -417,7 +460,10 @@ struct crt_scene {
     std::vector<void*> image_mem;
     DevScene dev = {};
     crt_render_info render = {};
-    int stack_entries = 8;
+    int stack_entries = 8;           // LDS entries of the traversal stack (8 or 16)
+    int spill_entries = 0;           // entries beyond them, in global memory
+    int spill_threads = 0;
+    int* stack_spill = nullptr;
     int lds_scene_bytes = 0;         // field-major copy of nodes + prims + xforms
     int lds_flat_bytes = 0;          // flat mode: slot records + xforms
     bool can_lds = false, can_flat = false;
@@ -541,6 +587,7 @@ void free_scene(crt_scene* sc) {
     if (sc->blob) (void)hipFree(sc->blob);
     if (sc->partial) (void)hipFree(sc->partial);
     if (sc->ray_counter) (void)hipFree(sc->ray_counter);
+    if (sc->stack_spill) (void)hipFree(sc->stack_spill);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_mid) (void)hipEventDestroy(sc->ev_mid);
     if (sc->ev_stop) (void)hipEventDestroy(sc->ev_stop);
@@ -559,7 +606,7 @@ int kernel_mode(const crt_scene* sc) {
 
 template <int STACK>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
-    size_t lds = (size_t)kWaves * kWaveLdsBytes + (size_t)STACK * kBlock * sizeof(int);
+    size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)STACK * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
         hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
@@ -573,7 +620,7 @@ int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
     const int mode = kernel_mode(sc);
     if (mode == kModeFlat) {
-        size_t lds = (size_t)kWaves * kWaveLdsBytes + (size_t)sc->lds_flat_bytes;
+        size_t lds = (size_t)kWaves * wave_lds_bytes(kModeFlat) + (size_t)sc->lds_flat_bytes;
         switch (sc->flat.groups) {
         case 0: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A); break;
         case 1: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A); break;
@@ -582,12 +629,13 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
         CRT_HIP(hipGetLastError());
         return CRT_OK;
     }
-    switch (sc->stack_entries) {
-    case 8: return launch_tree<8>(sc, A, grid, mode);
-    case 16: return launch_tree<16>(sc, A, grid, mode);
-    case 32: return launch_tree<32>(sc, A, grid, mode);
-    default: return launch_tree<64>(sc, A, grid, mode);
-    }
+    return sc->stack_entries == 8 ? launch_tree<8>(sc, A, grid, mode) : launch_tree<16>(sc, A, grid, mode);
+}
+
+bool node_is_leafy(const crt_bvh4& b, int node) {
+    for (int i = 0; i < 4; i++)
+        if (b.object_index[node * 4 + i] >= 0) return true;
+    return false;
 }
 
 // Leaf slots in the order the reference's traversal visits them when every box is hit
@@ -634,8 +682,8 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (validate(d, bvh_depth, why) != CRT_OK) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: " + why);
     // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
     const int need = 3 * (bvh_depth - 1) + 1;
-    int stack_entries = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : need <= 64 ? 64 : 0;
-    if (!stack_entries) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: BVH deeper than 22 levels");
+    if (need > 256) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: BVH deeper than 86 levels");
+    const int stack_entries = need <= 8 ? 8 : 16;
 
     const int nodes = d->bvh.slot_count / 4;
     // ---- repack: nodes (node-major, 8 float4), prims, shade, xforms (deduplicated), mats, texs
@@ -649,9 +697,41 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
                 rec[(3 + a) * 4 + i] = d->bvh.max_bounds[3 * s + a];
             }
             int o = d->bvh.object_index[s], c = d->bvh.children[s];
-            int32_t code = o >= 0 ? o : (c >= 0 ? -c - 2 : -1);
+            // slot code: object index, or -(2*child + leafy) - 2 for an internal slot, or -1 (empty);
+            // leafy = the child node has leaf slots of its own
+            int32_t code = o >= 0 ? o : (c >= 0 ? -(2 * c + (node_is_leafy(d->bvh, c) ? 1 : 0)) - 2 : -1);
             rec[6 * 4 + i] = as_float(code);
         }
+        // Visiting order of the four slots for each of the 8 direction octants (bit 0/1/2 set:
+        // the ray runs towards -x/-y/-z): slots sorted by their box centre along the octant's
+        // diagonal, nearest first; 2 bits per slot, one byte per octant.
+        uint32_t words[2] = {0, 0};
+        for (int oct = 0; oct < 8; oct++) {
+            float key[4];
+            int idx[4] = {0, 1, 2, 3};
+            for (int i = 0; i < 4; i++) {
+                const int s = n * 4 + i;
+                float k = 0.0f;
+                for (int a = 0; a < 3; a++) {
+                    const float c = 0.5f * (d->bvh.min_bounds[3 * s + a] + d->bvh.max_bounds[3 * s + a]);
+                    k += ((oct >> a) & 1) ? -c : c;
+                }
+                key[i] = std::isfinite(k) ? k : INFINITY;            // empty slots last
+            }
+            std::stable_sort(idx, idx + 4, [&](int a, int b) { return key[a] < key[b]; });
+            const uint32_t byte = (uint32_t)(idx[0] | (idx[1] << 2) | (idx[2] << 4) | (idx[3] << 6));
+            words[oct >> 2] |= byte << ((oct & 3) * 8);
+        }
+        rec[7 * 4 + 0] = as_float((int32_t)words[0]);
+        rec[7 * 4 + 1] = as_float((int32_t)words[1]);
+    }
+    // position of every object in the reference's leaf visiting order (tie rule of the closest hit)
+    std::vector<int> leaf_slots;
+    reference_visit_order(d->bvh, leaf_slots);
+    std::vector<int32_t> visit_rank((size_t)d->object_count, 0);
+    for (size_t rank = 0; rank < leaf_slots.size(); rank++) {
+        const int oi = d->bvh.object_index[leaf_slots[rank]];
+        if (oi >= 0 && oi < d->object_count) visit_rank[(size_t)oi] = (int32_t)rank;
     }
     std::vector<float> xforms;
     std::vector<float> prim_rec((size_t)d->object_count * kPrimQuads * 4, 0.0f), shade_rec((size_t)d->object_count * kShadeQuads * 4, 0.0f);
@@ -678,7 +758,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
             p[0] = o.p0[0]; p[1] = o.p0[1]; p[2] = o.p0[2]; p[3] = o.p2[0];
             p[4] = o.p1[0]; p[5] = o.p1[1]; p[6] = o.p1[2];
         }
-        p[9] = as_float(xf); p[10] = as_float(o.type);
+        p[9] = as_float(xf); p[10] = as_float(o.type); p[11] = as_float(visit_rank[(size_t)i]);
         float* s = &shade_rec[(size_t)i * kShadeQuads * 4];
         s[0] = o.n0[0]; s[1] = o.n0[1]; s[2] = o.n0[2]; s[3] = as_float(o.mat_idx);
         s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2]; s[7] = as_float(o.normal_idx);
@@ -712,8 +792,6 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     }
 
     // ---- flat mode (small scenes): box slots, see pt_device.h "flat traversal"
-    std::vector<int> leaf_slots;
-    reference_visit_order(d->bvh, leaf_slots);
     std::vector<float> flat_box_rec, flat_slot_rec, flat_group_xf;
     std::vector<int32_t> flat_ent_obj;
     int flat_groups = 0, flat_group_end[kMaxFlatGroups + 1] = {0, 0, 0};
@@ -836,6 +914,11 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
+    sc->spill_entries = std::max(0, need - stack_entries);
+    sc->spill_threads = std::max(sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves), 1024) * kBlock;
+    if (sc->spill_entries > 0) {
+        CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
+    }
 #undef CRT_HIP_OR_FREE
     uint8_t* base = static_cast<uint8_t*>(sc->blob);
     DevScene& D = sc->dev;
@@ -855,6 +938,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     D.width = d->render.image_width;
     D.height = d->render.image_height;
     D.max_bounces = d->render.max_bounces;
+    D.root_entry = node_is_leafy(d->bvh, 0) ? 1 : 0;
     const crt_camera& c = d->camera;
     D.cam.type = c.type;
     D.cam.defocus_angle = c.defocus_angle;
@@ -870,7 +954,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     sc->stack_entries = stack_entries;
     sc->lds_scene_bytes = (int)(((size_t)nodes * kNodeFields + (size_t)d->object_count * kPrimQuads) * 16 + xforms.size() * 4);
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
-    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + (size_t)kWaves * kWaveLdsBytes <= 40 * 1024;
+    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
     sc->can_flat = can_flat;
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
@@ -964,13 +1048,14 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     CRT_HIP(hipSetDevice(sc->device));
     RenderArgs A;
     A.sc = sc->dev;
-    A.tiles_x = (sc->dev.width + 7) / 8;
-    A.tiles_y = (sc->dev.height + 7) / 8;
+    const int tile_h = tile_rows(kernel_mode(sc));
+    A.tiles_x = (sc->dev.width + kTileW - 1) / kTileW;
+    A.tiles_y = (sc->dev.height + tile_h - 1) / tile_h;
     A.ntiles = A.tiles_x * A.tiles_y;
-    A.pix_padded = A.ntiles * 64;
-    // Work items: every 8x8 tile x a chunk of the samples.  About 32 items per resident wave keep
+    A.pix_padded = A.ntiles * kTileW * tile_h;
+    // Work items: every 8x4 tile x a chunk of the samples.  About 16 items per resident wave keep
     // the end of the launch (waves running dry one by one) to a few percent of its length.
-    int target_waves = 131072;
+    int target_waves = 65536;
     if (const char* e = std::getenv("CRT_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
     int chunks = std::min(samples, std::max(1, (target_waves + A.ntiles - 1) / A.ntiles));
     A.chunk_size = (samples + chunks - 1) / chunks;
@@ -988,13 +1073,19 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     }
     A.partial = sc->partial;
     A.chunks = chunks;
+    A.stack_spill = sc->stack_spill;
+    A.spill_threads = sc->spill_threads;
+    A.prim_batch = 8;
+    if (const char* e = std::getenv("CRT_PRIM_BATCH")) A.prim_batch = std::min(64, std::max(1, std::atoi(e)));
+    A.ready_percent = 50;
+    if (const char* e = std::getenv("CRT_READY_PERCENT")) A.ready_percent = std::min(100, std::max(1, std::atoi(e)));
     A.ray_counter = sc->ray_counter;
     A.queue = reinterpret_cast<unsigned int*>(sc->ray_counter + 1);
     CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, 2 * sizeof(unsigned long long), sc->stream));
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
     const long long items = (long long)A.ntiles * chunks;
     int resident = sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves);   // 4 SIMDs per CU
-    if (const char* e = std::getenv("CRT_BLOCKS")) resident = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("CRT_BLOCKS")) resident = std::min(sc->spill_threads / kBlock, std::max(1, std::atoi(e)));
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
     int rc = launch_fused(sc, A, grid);
@@ -1004,7 +1095,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     R.partial = sc->partial;
     R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
     R.depth = buf->depth(); R.opacity = buf->opacity();
-    R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = A.tiles_x; R.ntiles = A.ntiles; R.pix_padded = A.pix_padded;
+    R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = A.tiles_x; R.tile_rows = tile_h; R.ntiles = A.ntiles; R.pix_padded = A.pix_padded;
     R.chunks = chunks;
     R.done = (float)fold_done;
     R.count = (float)samples;
@@ -1109,8 +1200,10 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
     A.u = A.t + n;
     A.v = A.u + n;
     A.front = reinterpret_cast<int32_t*>(A.v + n);
-    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    dim3 grid((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)sc->spill_threads / kBlock));
     A.flat = sc->flat;
+    A.stack_spill = sc->stack_spill;
+    A.spill_threads = sc->spill_threads;
     if (kernel_mode(sc) == kModeFlat) {
         const size_t lds = (size_t)sc->lds_flat_bytes;
         switch (sc->flat.groups) {
@@ -1119,12 +1212,8 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
         default: hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0, 2>), grid, dim3(kBlock), lds, sc->stream, A); break;
         }
     } else {
-        switch (sc->stack_entries) {
-        case 8: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A); break;
-        case 16: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16, 0>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A); break;
-        case 32: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 32, 0>), grid, dim3(kBlock), 32 * kBlock * 4, sc->stream, A); break;
-        default: hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 64, 0>), grid, dim3(kBlock), 64 * kBlock * 4, sc->stream, A); break;
-        }
+        if (sc->stack_entries == 8) hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A);
+        else hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16, 0>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);

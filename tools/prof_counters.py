@@ -5,6 +5,10 @@ import numpy as np
 import cudaraytracer_amd as crt
 from cudaraytracer_amd import api
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
+if name == "mesh1m.yaml" and not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "scenes", "assets", "objects", "grid708.obj")):
+    import subprocess
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "make_mesh.py"), "grid", "708",
+                           os.path.join(os.path.dirname(__file__), "..", "scenes", "assets", "objects", "grid708.obj")])
 sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name), base_dir=os.path.join(os.path.dirname(__file__), "..", "scenes"))
 if len(sys.argv) > 2:
     sc.set_render(samples=int(sys.argv[2]))

@@ -6,7 +6,18 @@ from cudaraytracer_amd import api
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if name == "mesh1m.yaml" and not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "scenes", "assets", "objects", "grid708.obj")):
+    import subprocess
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "make_mesh.py"), "grid", "708",
+                           os.path.join(os.path.dirname(__file__), "..", "scenes", "assets", "objects", "grid708.obj")])
+t_load = time.time()
 sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name), base_dir=os.path.join(os.path.dirname(__file__), "..", "scenes"))
+if len(sys.argv) > 3:
+    sc.set_render(samples=int(sys.argv[3]))
+print(f"{name}: scene load + BVH build {time.time() - t_load:.2f} s, {sc.desc.object_count} objects", flush=True)
+t_up = time.time()
+sc.upload()
+print(f"{name}: upload {time.time() - t_up:.2f} s", flush=True)
 buf = crt.create_buffer(sc)
 for r in range(reps):
     t0 = time.time()
