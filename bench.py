@@ -34,6 +34,16 @@ PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 peak
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak
 
 
+def measured_traffic(scene):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate
+    rocprofv3 --pmc runs, corrected as the gfx950 notes prescribe); None if not measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[scene]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene_file, width, height, spp, threads):
     """Oracle (CPU restatement of the reference) timed on the host cores on a bounded sample of
     the same workload: the full-size image at a reduced sample count."""
@@ -142,7 +152,7 @@ def main():
             achieved = rays_per_launch * flops / (kernel_ms * 1e-3) / 1e12
             hbm = rays_per_launch * BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
             roofline = {"bound": "valu", "kernel": "render_fused", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": measured_traffic(args.scene),
                         "kernel_ms": round(kernel_ms, 4), "rays_per_launch": int(rays_per_launch),
                         "flops_per_ray": flops,
                         "hbm": {"achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
