@@ -1,0 +1,156 @@
+"""Edge cases of the boundary: descriptions the library must refuse (checked before any device
+call, so these run without a GPU), and on the GPU the sizes and limits the reference's render()
+handles: image sizes that are not a multiple of the tile, a single pixel, no objects at all,
+max_bounces 0 and 1, sample counts beyond samples_per_pixel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import scene_path
+
+MINI = """
+camera: {type: perspective, from: [0, 0, 5], to: [0, 0, 0], vfov: 40}
+render: {width: 13, height: 7, samples: 3, max_bounces: 4}
+environment:
+  texture: {type: solid_color, color: [0.2, 0.4, 0.8]}
+objects:
+  - type: sphere
+    center: [0, 0, 0]
+    radius: 1
+    material: {type: lambertian, texture: {type: solid_color, color: [0.8, 0.3, 0.3]}}
+"""
+EMPTY = """
+camera: {type: orthographic, from: [0, 0, 5], to: [0, 0, 0], width: 4}
+render: {width: 9, height: 5, samples: 2, max_bounces: 3}
+environment:
+  texture: {type: solid_color, color: [0.25, 0.5, 0.75]}
+objects: []
+"""
+
+
+def clone(desc):
+    out = type(desc)()
+    C.memmove(C.byref(out), C.byref(desc), C.sizeof(desc))
+    return out
+
+
+def create(crt, desc):
+    h = C.c_void_p()
+    rc = crt.lib().crt_scene_create(C.byref(desc), C.byref(h))
+    return rc, crt.lib().crt_last_error().decode()
+
+
+def test_invalid_descriptions_are_refused(crt):
+    sc = crt.parse_scene(MINI)
+    base = sc.desc
+    lib = crt.lib()
+
+    d = clone(base); d.background_index = 7
+    rc, msg = create(crt, d)
+    assert rc == -1 and "background_index" in msg
+    d = clone(base); d.render.image_width = 0
+    assert create(crt, d)[0] == -1
+    d = clone(base); d.render.max_bounces = -1
+    assert create(crt, d)[0] == -1
+    d = clone(base); d.camera.type = 9
+    assert create(crt, d)[0] == -1
+
+    objs = (type(base.objects.contents) * 1)()
+    C.memmove(objs, base.objects, C.sizeof(objs))
+    objs[0].mat_idx = 5
+    d = clone(base); d.objects = C.cast(objs, type(base.objects))
+    rc, msg = create(crt, d)
+    assert rc == -1 and "material index" in msg
+
+    n = base.bvh.slot_count
+    children = (C.c_int32 * n)(*[base.bvh.children[i] for i in range(n)])
+    children[0] = 0                                              # the root as its own child
+    d = clone(base); d.bvh.children = C.cast(children, type(base.bvh.children))
+    rc, msg = create(crt, d)
+    assert rc == -1 and "BVH" in msg
+    oi = (C.c_int32 * n)(*[base.bvh.object_index[i] for i in range(n)])
+    oi[0] = 99
+    d = clone(base); d.bvh.object_index = C.cast(oi, type(base.bvh.object_index))
+    assert create(crt, d)[0] == -1
+
+    assert lib.crt_scene_create(None, None) == -1
+    assert lib.crt_render(None, None, 1, 0, None, None) == -1
+    assert lib.crt_buffers_create(0, 5, C.byref(C.c_void_p())) == -1
+    sc.close()
+
+
+def test_scene_without_objects_parses(crt):
+    sc = crt.parse_scene(EMPTY)
+    d = sc.desc
+    assert d.object_count == 0 and d.bvh.slot_count == 4
+    assert all(d.bvh.object_index[i] == -1 and d.bvh.children[i] == -1 for i in range(4))
+    sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_odd_sizes_and_limits_on_gpu(crt, oracle, mode):
+    from cudaraytracer_amd import api
+
+    def compare(sc, w, h, samples, bounces):
+        sc.set_render(w, h, samples, bounces)
+        sc.set_mode(mode)
+        dp = crt.lib().crt_host_scene_desc(sc._host)
+        buf = crt.create_buffer(sc)
+        ref = oracle_lib.new_passes(w, h)
+        for done in range(samples):
+            crt.render(sc, buf, samples=1, samples_done=done)
+            oracle_lib.render(oracle, dp, w, h, samples=1, samples_done=done, passes=ref)
+        got = buf.download()
+        for k in oracle_lib.PASSES:
+            a, b = got[k], ref[k]
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (w, h, samples, bounces, k)
+        buf.close()
+
+    sc = crt.parse_scene(MINI)
+    for w, h in ((13, 7), (1, 1), (8, 8), (9, 1), (1, 9), (65, 33)):
+        compare(sc, w, h, 3, 4)
+    compare(sc, 13, 7, 2, 1)                                     # one bounce: every path scatters once and is exhausted
+    # samples beyond samples_per_pixel are clamped (render.cuh:120-124)
+    sc.set_render(13, 7, 3, 4)
+    buf = crt.create_buffer(sc)
+    crt.render(sc, buf, samples=100)
+    full = api.last_ray_count
+    crt.render(sc, buf, samples=-1)
+    assert api.last_ray_count == full
+    # a buffer of another size is refused
+    other = crt.Buffer(5, 5)
+    with pytest.raises(crt.CrtError):
+        crt.render(sc, other)
+    other.close()
+    buf.close()
+    sc.close()
+
+    empty = crt.parse_scene(EMPTY)
+    empty.set_mode(mode)
+    buf = crt.create_buffer(empty)
+    crt.render(empty, buf)
+    got = buf.download()
+    assert api.last_ray_count == 9 * 5 * 2
+    assert np.allclose(got["color"], [0.25, 0.5, 0.75]) and np.allclose(got["albedo"], [0.25, 0.5, 0.75])
+    assert np.isnan(got["depth"]).all() and (got["opacity"] == 0).all() and (got["normal"] == 0).all()
+    buf.close()
+    empty.close()
+
+
+@pytest.mark.gpu
+def test_zero_bounces_renders_black(crt):
+    """max_bounces 0: the path loop never runs; colour and albedo are 0 (render.cuh:96-97) and no
+    ray is traced.  (The reference leaves depth and opacity uninitialised in that case; here they
+    are 0.)"""
+    sc = crt.parse_scene(MINI.replace("max_bounces: 4", "max_bounces: 0"))
+    buf = crt.create_buffer(sc)
+    crt.render(sc, buf)
+    from cudaraytracer_amd import api
+    got = buf.download()
+    assert api.last_ray_count == 0
+    assert (got["color"] == 0).all() and (got["albedo"] == 0).all() and (got["opacity"] == 0).all()
+    buf.close()
+    sc.close()
