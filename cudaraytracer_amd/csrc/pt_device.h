@@ -130,6 +130,7 @@ struct DevScene {
     int32_t node_count, object_count, xform_count, material_count, texture_count, background_index;
     int32_t width, height, max_bounces;
     int32_t root_entry;       // stack entry of BVH node 0: leafy flag in bit 0
+    int32_t fast_rcp;         // the host proved reciprocal()'s fast form exact for this scene (selects the kernel variant)
     DevCamera cam;
 };
 
@@ -250,18 +251,38 @@ struct Hit {
     float bu, bv;  // triangle barycentrics
 };
 
+// 1.0f / x.  With `fast` set (a compile-time constant at every call site): v_rcp_f32 plus one Newton step (two FMAs) instead of the general
+// division sequence.  For every float with 2^-100 <= |x| <= 2^100 that is bit-identical to the
+// IEEE quotient (checked over all 2^32 inputs on gfx950, tools/ubench/rcp_exhaustive.hip).  The
+// host sets `fast` only for scenes whose geometry bounds every divisor used on the path into
+// that range (see fast_reciprocal_is_exact()); otherwise the ordinary division runs.
+__device__ __forceinline__ float reciprocal(float x, int fast) {
+    if (fast) {
+        const float r0 = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r0, 1.0f);
+        return __builtin_fmaf(e, r0, r0);
+    }
+    return 1.0f / x;
+}
+
 __device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3& oo, V3& od) {   // hittable.cuh:429-430
     V3 anchor = v3(xf[9], xf[10], xf[11]), trans = v3(xf[12], xf[13], xf[14]);
     oo = matvec(xf, o - anchor - trans) + anchor;
     od = matvec(xf, d);
 }
 
+// aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
+__device__ __forceinline__ V3 slab_reciprocal(V3 d, int fast) {
+    return v3((fabsf(d.x) > 1e-12f) ? reciprocal(d.x, fast) : 1e8f, (fabsf(d.y) > 1e-12f) ? reciprocal(d.y, fast) : 1e8f,
+              (fabsf(d.z) > 1e-12f) ? reciprocal(d.z, fast) : 1e8f);
+}
+
 // hit_tri, hittable.cuh:314-335 (acceptance part).  Interval test is inclusive.
-__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax, float& t, float& bu, float& bv) {
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax, int fast, float& t, float& bu, float& bv) {
     V3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     if (fabsf(det) < 1e-8f) return false;
-    float inv_det = 1.0f / det;
+    float inv_det = reciprocal(det, fast);
     V3 tvec = o - point;
     float u = dot(tvec, pvec) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
@@ -346,7 +367,7 @@ struct TreeState {
     __device__ __forceinline__ Hit result() const { Hit h = best; h.obj = best_obj; return h; }
 };
 
-template <class Mem>
+template <int FAST, class Mem>
 __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, float tmin, TreeState& ts) {
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
     const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
@@ -355,7 +376,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
     const int before = ts.best.obj;
     if (type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
-        const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, t, bu, bv);
+        const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, FAST, t, bu, bv);
         consider(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
     } else {
         // the root the reference would take does not depend on the interval's upper end: the
@@ -375,12 +396,10 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
 //   * leaf candidates are tested, one per lane, once at least `prim_batch` lanes hold some (or
 //     nobody can take a node step): the long intersection code then runs for a batch of lanes
 //     instead of the one or two that happen to reach a leaf in a given round.
-template <class Mem>
+template <int FAST, class Mem>
 __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin, TreeState& ts, bool& walking, LaneStack stk, int min_active, int prim_batch) {
-    // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
-    const float ix = (fabsf(r.d.x) > 1e-12f) ? (1.0f / r.d.x) : 1e8f;
-    const float iy = (fabsf(r.d.y) > 1e-12f) ? (1.0f / r.d.y) : 1e8f;
-    const float iz = (fabsf(r.d.z) > 1e-12f) ? (1.0f / r.d.z) : 1e8f;
+    const V3 inv = slab_reciprocal(r.d, FAST);
+    const float ix = inv.x, iy = inv.y, iz = inv.z;
     // field numbers of the near / far planes per axis (swap when the reciprocal is negative)
     const int nx = ix < 0.0f ? 3 : 0, fx = 3 - nx;
     const int ny = iy < 0.0f ? 4 : 1, fy = 5 - ny;
@@ -448,7 +467,7 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 // an earlier candidate may have shrunk the interval below this box's entry
                 if (!(ts.best.t < lo)) {
                     CRT_PROF(kProfPrim);
-                    tree_prim(S, code, r, tmin, ts);
+                    tree_prim<FAST>(S, code, r, tmin, ts);
                 }
             }
         }
@@ -463,7 +482,7 @@ __device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, 
     TreeState ts;
     ts.begin(tmax, S.root_entry);
     bool walking = true;
-    tree_run(S, r, tmin, ts, walking, stk, 1, 16);
+    tree_run<0>(S, r, tmin, ts, walking, stk, 1, 16);
     return ts.result();
 }
 
@@ -532,10 +551,6 @@ __device__ __forceinline__ unsigned flat_box_hit(NativeQuad b0, NativeQuad b1, V
     const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return (hi < lo) ? 0u : 1u;
 }
-__device__ __forceinline__ V3 slab_reciprocal(V3 d) {                       // aabb.cuh:140
-    return v3((fabsf(d.x) > 1e-12f) ? (1.0f / d.x) : 1e8f, (fabsf(d.y) > 1e-12f) ? (1.0f / d.y) : 1e8f,
-              (fabsf(d.z) > 1e-12f) ? (1.0f / d.z) : 1e8f);
-}
 // Box tests of slots [first, last) -> bits shifted into (hi:lo) from the right, so that slot s
 // ends up at bit (slot_count-1-s): the first slot is the highest set bit.
 __device__ __forceinline__ void flat_box_range(ConstQuadPtr boxes, int first, int last, V3 o, V3 inv, float tmin,
@@ -553,12 +568,12 @@ struct TriEval {
     float t, u, v;
 };
 // hit_tri (hittable.cuh:314-335) without early exits: same tests, same arithmetic.
-__device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax) {
+__device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, float tmin, float tmax, int fast) {
     TriEval r;
     V3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     bool ok = !(fabsf(det) < 1e-8f);
-    float inv_det = 1.0f / det;
+    float inv_det = reciprocal(det, fast);                       // never read for a rejected candidate
     V3 tvec = o - point;
     r.u = dot(tvec, pvec) * inv_det;
     ok = ok && !(r.u < 0.0f || r.u > 1.0f);
@@ -570,12 +585,12 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
     return r;
 }
 
-template <int GROUPS>
+template <int GROUPS, int FAST>
 __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax, SectionClock& clk) {
     ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
     unsigned cand_lo = 0, cand_hi = 0;
-    flat_box_range(boxes, 0, F.group_end[0], r.o, slab_reciprocal(r.d), tmin, cand_lo, cand_hi);
+    flat_box_range(boxes, 0, F.group_end[0], r.o, slab_reciprocal(r.d, FAST), tmin, cand_lo, cand_hi);
     // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
     V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
     if constexpr (GROUPS >= 1) {
@@ -583,14 +598,14 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
 #pragma unroll
         for (int k = 0; k < 15; k++) X[k] = gx[k];
         to_object_space(X, r.o, r.d, o1, d1);
-        flat_box_range(boxes, F.group_end[0], F.group_end[1], o1, slab_reciprocal(d1), tmin, cand_lo, cand_hi);
+        flat_box_range(boxes, F.group_end[0], F.group_end[1], o1, slab_reciprocal(d1, FAST), tmin, cand_lo, cand_hi);
     }
     if constexpr (GROUPS >= 2) {
         float X[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) X[k] = gx[kXformFloats + k];
         to_object_space(X, r.o, r.d, o2, d2);
-        flat_box_range(boxes, F.group_end[1], F.group_end[2], o2, slab_reciprocal(d2), tmin, cand_lo, cand_hi);
+        flat_box_range(boxes, F.group_end[1], F.group_end[2], o2, slab_reciprocal(d2, FAST), tmin, cand_lo, cand_hi);
     }
 
     Hit best;
@@ -618,8 +633,8 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         CRT_MARK("prim_test");
         if (is_tri) {
             // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
-            TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax);
-            TriEval B = tri_eval(o, d, v3(q0.y, q0.w, q1.y), v3(q1.w, q2.y, q2.w), v3(q3.y, q3.w, q4.y), tmin, tmax);
+            TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax, FAST);
+            TriEval B = tri_eval(o, d, v3(q0.y, q0.w, q1.y), v3(q1.w, q2.y, q2.w), v3(q3.y, q3.w, q4.y), tmin, tmax, FAST);
             consider(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
             consider(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
         } else {

@@ -124,7 +124,7 @@ struct WorkItem {
 // left.  A wave keeps TWO items open: lanes whose path ended take new paths from the `fill`
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
-template <int MODE, int STACK, int GROUPS>
+template <int MODE, int STACK, int GROUPS, int FAST>
 __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
     constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
     constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             CRT_CLOCK(clk, kSecNode, ray.o.y);
             const int living = __builtin_popcountll(__ballot(alive));
             const int ready_target = max(1, living * A.ready_percent / 100);
-            if constexpr (MODE == kModeTreeLds) tree_run(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
-            else tree_run(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            if constexpr (MODE == kModeTreeLds) tree_run<FAST>(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            else tree_run<FAST>(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
             ready = alive && !walking;
         }
         if (ready) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             CRT_MARK("trace");
             if constexpr (MODE == kModeFlat) {
                 CRT_CLOCK(clk, kSecBox, ray.o.y);
-                h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+                h = traverse_flat<GROUPS, FAST>(FL, A.flat, ray, 0.001f, INFINITY, clk);
             } else {
                 h = ts.result();
             }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
         if constexpr (MODE == kModeFlat) {
             SectionClock clk;
             clk.start();
-            h = traverse_flat<GROUPS>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+            h = traverse_flat<GROUPS, 0>(FL, A.flat, ray, 0.001f, INFINITY, clk);
             if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
         } else {
             SceneGlobal S;
@@ -604,17 +604,23 @@ int kernel_mode(const crt_scene* sc) {
     }
 }
 
-template <int STACK>
+template <int STACK, int FAST>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)STACK * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
-        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0, FAST>), grid, dim3(kBlock), lds, sc->stream, A);
     } else {
-        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK, 0, FAST>), grid, dim3(kBlock), lds, sc->stream, A);
     }
     CRT_HIP(hipGetLastError());
     return CRT_OK;
+}
+
+template <int GROUPS>
+void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
+    if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1>), grid, dim3(kBlock), lds, sc->stream, A);
+    else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0>), grid, dim3(kBlock), lds, sc->stream, A);
 }
 
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
@@ -622,14 +628,47 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
     if (mode == kModeFlat) {
         size_t lds = (size_t)kWaves * wave_lds_bytes(kModeFlat) + (size_t)sc->lds_flat_bytes;
         switch (sc->flat.groups) {
-        case 0: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A); break;
-        case 1: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A); break;
-        default: hipLaunchKernelGGL((render_fused<kModeFlat, 0, 2>), grid, dim3(kBlock), lds, sc->stream, A); break;
+        case 0: launch_flat<0>(sc, A, grid, lds); break;
+        case 1: launch_flat<1>(sc, A, grid, lds); break;
+        default: launch_flat<2>(sc, A, grid, lds); break;
         }
         CRT_HIP(hipGetLastError());
         return CRT_OK;
     }
-    return sc->stack_entries == 8 ? launch_tree<8>(sc, A, grid, mode) : launch_tree<16>(sc, A, grid, mode);
+    if (sc->dev.fast_rcp) return sc->stack_entries == 8 ? launch_tree<8, 1>(sc, A, grid, mode) : launch_tree<16, 1>(sc, A, grid, mode);
+    return sc->stack_entries == 8 ? launch_tree<8, 0>(sc, A, grid, mode) : launch_tree<16, 0>(sc, A, grid, mode);
+}
+
+// True when every divisor the kernels invert on the path (triangle determinants that pass the
+// 1e-8 test, ray direction components beyond 1e-12) is guaranteed to lie in [2^-100, 2^100],
+// where the Newton-refined hardware reciprocal equals the IEEE quotient bit for bit.  The lower
+// ends are the path's own thresholds; the upper ends follow from the scene: a direction is a
+// camera ray (bounded by the view plane), normal + unit vector, a reflection + fuzz * unit-ball
+// vector or a refraction, possibly taken through an object's inverse rotation, and
+// |det| = |e1 . (d x e2)| <= |e1| |e2| |d|.
+bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
+    auto len = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
+    const crt_camera& c = d->camera;
+    double dir = 2.5;
+    if (c.type == CRT_CAM_PERSPECTIVE) {
+        const float to_corner[3] = {c.lower_left_corner[0] - c.center[0], c.lower_left_corner[1] - c.center[1], c.lower_left_corner[2] - c.center[2]};
+        dir = std::max(dir, len(to_corner) + (d->render.image_width + 1.0) * len(c.pixel_delta_u) + (d->render.image_height + 1.0) * len(c.pixel_delta_v) +
+                                2.0 * (len(c.defocus_disk_u) + len(c.defocus_disk_v)));
+    } else {
+        dir = std::max(dir, len(c.w));
+    }
+    for (int i = 0; i < d->material_count; i++)
+        if (d->materials[i].type == CRT_MAT_METAL) dir = std::max(dir, 1.0 + std::fabs((double)d->materials[i].fuzz));
+    double rot = 1.0, edges = 0.0;
+    for (int i = 0; i < d->object_count; i++) {
+        const crt_object& o = d->objects[i];
+        double f = 0.0;
+        for (int k = 0; k < 9; k++) f += (double)o.rotation_inv[k] * o.rotation_inv[k];
+        rot = std::max(rot, std::sqrt(f));
+        if (o.type == CRT_OBJ_TRI) edges = std::max(edges, len(o.p1) * len(o.p2));
+    }
+    const double dir_object = dir * rot;
+    return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p90 && edges * dir_object < 0x1p99;
 }
 
 bool node_is_leafy(const crt_bvh4& b, int node) {
@@ -939,6 +978,8 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     D.height = d->render.image_height;
     D.max_bounces = d->render.max_bounces;
     D.root_entry = node_is_leafy(d->bvh, 0) ? 1 : 0;
+    D.fast_rcp = fast_reciprocal_is_exact(d) ? 1 : 0;
+    if (const char* e = std::getenv("CRT_FAST_RCP")) D.fast_rcp = std::atoi(e) ? D.fast_rcp : 0;   // 0 forces IEEE division
     const crt_camera& c = d->camera;
     D.cam.type = c.type;
     D.cam.defocus_angle = c.defocus_angle;

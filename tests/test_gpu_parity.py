@@ -227,3 +227,37 @@ def test_feature_scenes_bit_exact(crt, oracle, name, mode):
     assert rays == 0
     buf.close()
     sc.close()
+
+
+def test_fast_reciprocal_variant_is_bit_identical(crt):
+    """Kernels for scenes with bounded divisors replace 1/x by v_rcp_f32 + one Newton step.  (a) The
+    refined reciprocal equals the IEEE quotient for every float in [2^-100, 2^100]: exhaustive
+    run over all 2^32 inputs.  (b) Both kernel variants give the same image bit for bit."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "ubench", "rcp_exhaustive")
+    assert os.path.exists(exe), "build it with make -C tools/ubench"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    assert "reciprocal, one Newton step:  0 mismatches" in out, out
+    assert "division via reciprocal (1 step): 0 mismatches" in out, out
+    assert "raw v_rcp_f32 (control): 0 mismatches" not in out          # the check can fail
+
+    images = []
+    for flag in ("1", "0"):
+        os.environ["CRT_FAST_RCP"] = flag
+        try:
+            for name, mode in (("cornell_box.yaml", 0), ("features_tree.yaml", 1)):
+                sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
+                sc.set_render(128, 96, samples=6)
+                sc.set_mode(mode)
+                buf = crt.create_buffer(sc)
+                crt.render(sc, buf)
+                images.append(buf.download())
+                buf.close()
+                sc.close()
+        finally:
+            del os.environ["CRT_FAST_RCP"]
+    for fast, ieee in ((images[0], images[2]), (images[1], images[3])):
+        for k in oracle_lib.PASSES:
+            assert np.array_equal(fast[k].view(np.uint32), ieee[k].view(np.uint32)), k
