@@ -30,11 +30,17 @@
 
 namespace crt {
 
-// Profiling build (-DCRT_PROFILE): wave-level iteration counts and active-lane sums of the
-// kernel's loops, accumulated in a device array (slot 2k = times the wave executed site k,
-// slot 2k+1 = lanes active there).  Compiled out of the product build.
+// Profiling builds (never the product build):
+//   -DCRT_PROFILE                      wave-level iteration counts and active-lane sums of the kernel's
+//                                      loops in a device array (slot 2k = times a wave executed site k,
+//                                      slot 2k+1 = lanes active there);
+//   -DCRT_PROFILE -DCRT_PROFILE_CLOCK  instead, the shader-clock time of the waves per section of the
+//                                      path loop (slots 32..39); the counters' atomics would dominate
+//                                      those times, so the two are separate builds.
 #ifdef CRT_PROFILE
 __device__ unsigned long long g_prof[64];
+#endif
+#if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
 __device__ __forceinline__ void prof_tick(int site) {
     unsigned long long m = __ballot(1);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) {
@@ -42,12 +48,11 @@ __device__ __forceinline__ void prof_tick(int site) {
         atomicAdd(&g_prof[2 * site + 1], (unsigned long long)__builtin_popcountll(m));
     }
 }
-#ifdef CRT_PROFILE_CLOCK        // the counters' atomics would dominate the section times
-#define CRT_PROF(site) ((void)0)
-#else
 #define CRT_PROF(site) prof_tick(site)
+#else
+#define CRT_PROF(site) ((void)0)
 #endif
-// Shader-clock time of a wave per section of the path loop (slots 16.. of g_prof).
+#ifdef CRT_PROFILE_CLOCK
 struct SectionClock {
     unsigned long long last, acc[8];
     int cur;
@@ -76,13 +81,8 @@ struct SectionClock {
             for (int k = 0; k < 8; k++) atomicAdd(&g_prof[32 + k], acc[k]);
     }
 };
-#ifdef CRT_PROFILE_CLOCK
 #define CRT_CLOCK(clk, section, dep) (clk).mark(section, dep)
 #else
-#define CRT_CLOCK(clk, section, dep) ((void)0)
-#endif
-#else
-#define CRT_PROF(site) ((void)0)
 struct SectionClock {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void flush() {}
@@ -90,14 +90,8 @@ struct SectionClock {
 #define CRT_CLOCK(clk, section, dep) ((void)0)
 #endif
 enum { kSecOther = 0, kSecRegen = 1, kSecBox = 2, kSecPrim = 3, kSecSurface = 4, kSecSample = 5, kSecScatter = 6, kSecNode = 7 };
-// Analysis build (-DCRT_MARKS, assembly only): named comments in the ISA at section boundaries.
-#ifdef CRT_MARKS
-#define CRT_MARK(name) asm volatile("; CRTMARK " name)
-#else
-#define CRT_MARK(name) ((void)0)
-#endif
 enum { kProfOuter = 0, kProfRegen = 1, kProfTrace = 2, kProfNode = 3, kProfPrim = 4, kProfShade = 5, kProfReject = 6,
-       kProfXform = 7, kProfPush = 8 };
+       kProfXform = 7 };
 
 constexpr float kPi = 3.1415926535897932385f;
 constexpr int kNodeFields = 8;        // minx miny minz maxx maxy maxz code order   (float4 / int4 each)
@@ -518,7 +512,6 @@ __device__ __forceinline__ Hit traverse(const Mem& S, const Ray& r, float tmin, 
 typedef float NativeQuad __attribute__((ext_vector_type(4)));
 typedef const NativeQuad __attribute__((address_space(4))) * ConstQuadPtr;
 typedef const float __attribute__((address_space(4))) * ConstFloatPtr;
-typedef float NativePair __attribute__((ext_vector_type(2)));
 
 constexpr int kSlotQuads = 5;          // float4 per slot record of the primitive phase
 constexpr int kMaxFlatSlots = 64;
@@ -612,11 +605,9 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
     bool best_tri = false;
     const int n = L.slot_count;
-    CRT_MARK("prim_loop_head");
     CRT_CLOCK(clk, kSecPrim, cand_lo);
     while (cand_lo | cand_hi) {
         CRT_PROF(kProfPrim);
-        CRT_MARK("prim_body");
         int bit;
         if (cand_hi) { bit = 63 - __builtin_clz(cand_hi); cand_hi &= ~(1u << (bit - 32)); }
         else { bit = 31 - __builtin_clz(cand_lo); cand_lo &= ~(1u << bit); }
@@ -630,7 +621,6 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         if constexpr (GROUPS >= 1) { if (group == 1) { o = o1; d = d1; } }
         if constexpr (GROUPS >= 2) { if (group == 2) { o = o2; d = d2; } }
         if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(L.xforms + xf * kXformFloats, r.o, r.d, o, d); }
-        CRT_MARK("prim_test");
         if (is_tri) {
             // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
             TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax, FAST);
@@ -653,7 +643,6 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             consider(best, best_tri, ok, root, rank_a, false, 0.0f, 0.0f);
         }
     }
-    CRT_MARK("prim_done");
     return best;
 }
 

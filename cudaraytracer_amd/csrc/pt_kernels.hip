@@ -231,7 +231,6 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             const unsigned long long free_mask = __ballot(!alive);
             if (!alive) {
                 CRT_PROF(kProfRegen);
-                CRT_MARK("regen");
                 const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
                 if (item < fill.total) {
                     const int pix = item & (kTilePixels - 1);
@@ -250,7 +249,6 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                 }
             }
             fill.next += __builtin_popcountll(free_mask);
-            CRT_MARK("regen_done");
         }
         CRT_CLOCK(clk, kSecOther, ray.o.x);
         if (!__any(alive)) {
@@ -276,7 +274,6 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         if (ready) {
             rays++;
             CRT_PROF(kProfTrace);
-            CRT_MARK("trace");
             if constexpr (MODE == kModeFlat) {
                 CRT_CLOCK(clk, kSecBox, ray.o.y);
                 h = traverse_flat<GROUPS, FAST>(FL, A.flat, ray, 0.001f, INFINITY, clk);
@@ -286,7 +283,6 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             CRT_CLOCK(clk, kSecSurface, h.t);
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
-                CRT_MARK("surface");
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
                 sf = make_surface(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
@@ -294,10 +290,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             }
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
-        CRT_MARK("coop");
         CRT_CLOCK(clk, kSecSample, sf.p.x);
         const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
-        CRT_MARK("scatter");
         V3 rv_dep = rv;
         CRT_CLOCK(clk, kSecScatter, rv_dep.x);
         if (ready) {
@@ -345,7 +339,6 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                 alive = false;
             }
         }
-        CRT_MARK("iter_end");
         CRT_CLOCK(clk, kSecOther, throughput.x);
     }
     clk.flush();

@@ -37,7 +37,6 @@ CRT_HD V3 cross(V3 a, V3 b) {
 CRT_HD float length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 CRT_HD float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 CRT_HD V3 unit(V3 a) { return a / length(a); }
-CRT_HD float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // Row-major 3x3 times vector, rows summed left to right (mat3.cuh:82-86).
 CRT_HD V3 matvec(const float* m, V3 u) {

@@ -15,7 +15,7 @@ for CTRS in \
   "FETCH_SIZE" \
   "WRITE_SIZE" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/quick_perf.py $SCENE 1 > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/quick_perf.py $SCENE 1 ${3:-} > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections

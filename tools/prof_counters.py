@@ -19,7 +19,7 @@ secs = crt.render(sc, buf)
 out = np.zeros(64, np.uint64)
 lib.crt_profile_counters(out.ctypes.data, 0)
 rays = api.last_ray_count
-names = ["outer", "regen", "trace", "node", "prim", "shade", "reject", "xform", "push"]
+names = ["outer", "regen", "trace", "node", "prim", "shade", "reject", "xform"]
 print(f"{name}: rays {rays}")
 for k, n in enumerate(names):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
