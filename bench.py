@@ -73,6 +73,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result; anything native libraries print on the way
+    # (RCCL's version banner, for one) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import cudaraytracer_amd as crt
@@ -87,8 +93,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     crt.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK is set) the collective path runs even with one rank, so a
+    # single-GPU box can rehearse exactly what the N-GPU launch does
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     scene_file = os.path.join(ROOT, "scenes", args.scene)
@@ -104,7 +114,7 @@ def main():
     def step():
         first, count = multi_gpu.rank_sample_range(rank, world, spp)
         secs, rays = crt.render_range(sc, buf, first, count)
-        if world > 1:
+        if distributed:
             multi_gpu.combine_means(passes, count, spp * world, dist)
             torch.cuda.current_stream().synchronize()
         tr, rs = C.c_float(0), C.c_float(0)
@@ -113,7 +123,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,7 +141,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -170,11 +180,14 @@ def main():
         if world == 1 and args.cpu_spp > 0:
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(scene_file, W, H, args.cpu_spp, threads)
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     buf.close()
     sc.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -31,8 +31,9 @@ def combine_means(passes, count, total, dist=None):
     """In-place: passes (a torch tensor holding this rank's MEAN over `count` samples) becomes the
     mean over all `total` samples of all ranks.  `dist` is torch.distributed (initialised) or None
     for a single rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return passes
-    passes.mul_(float(count) / float(total))
+    if count != total:
+        passes.mul_(float(count) / float(total))
     dist.all_reduce(passes)
     return passes
