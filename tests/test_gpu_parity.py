@@ -261,3 +261,39 @@ def test_fast_reciprocal_variant_is_bit_identical(crt):
     for fast, ieee in ((images[0], images[2]), (images[1], images[3])):
         for k in oracle_lib.PASSES:
             assert np.array_equal(fast[k].view(np.uint32), ieee[k].view(np.uint32)), k
+
+
+def test_million_triangle_scene_bit_exact(crt, oracle, tmp_path):
+    """mesh1m.yaml (1 002 536 objects, BVH deeper than the 16 LDS stack entries, so the walks use
+    the global part of their stacks): hits and passes equal to the oracle's, sample by sample."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from cudaraytracer_amd import api
+    obj = os.path.join(str(tmp_path), "grid708.obj")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_mesh.py"), "grid", "708", obj])
+    text = open(scene_path("mesh1m.yaml")).read().replace("assets/objects/grid708.obj", obj)
+    sc = crt.parse_scene(text)
+    assert sc.desc.object_count == 1002536
+    w, h = 96, 64
+    sc.set_render(w, h, samples=3)
+    dp = _desc_ptr(crt, sc)
+    g = sc.trace_primary(1)
+    o = oracle_lib.trace_primary(oracle, dp, w, h, 1)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
+    assert (g[0] >= 8).any()                                    # some primary rays hit the mesh itself
+    buf = crt.create_buffer(sc)
+    ref = oracle_lib.new_passes(w, h)
+    for done in range(3):
+        crt.render(sc, buf, samples=1, samples_done=done)
+        rays = api.last_ray_count
+        got = buf.download()
+        _, stats = oracle_lib.render(oracle, dp, w, h, samples=1, samples_done=done, passes=ref)
+        assert rays == stats["rays"]
+        for k in oracle_lib.PASSES:
+            a, b = got[k], ref[k]
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"pass {k} differs after sample {done + 1}: {np.flatnonzero(~same)[:8]}"
+    buf.close()
+    sc.close()
