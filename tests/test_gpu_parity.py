@@ -297,3 +297,57 @@ def test_million_triangle_scene_bit_exact(crt, oracle, tmp_path):
             assert same.all(), f"pass {k} differs after sample {done + 1}: {np.flatnonzero(~same)[:8]}"
     buf.close()
     sc.close()
+
+
+TIES = """
+camera: {type: perspective, from: [0, 1, 6], to: [0, 1, 0], vfov: 40}
+render: {width: 64, height: 48, samples: 2, max_bounces: 4}
+environment:
+  texture: {type: solid_color, color: [0.6, 0.7, 0.9]}
+materials:
+  - {name: red, type: lambertian, texture: {type: solid_color, color: [0.9, 0.1, 0.1]}}
+  - {name: green, type: lambertian, texture: {type: solid_color, color: [0.1, 0.9, 0.1]}}
+  - {name: blue, type: lambertian, texture: {type: solid_color, color: [0.1, 0.1, 0.9]}}
+  - {name: mirror, type: metal, color: [0.9, 0.9, 0.9]}
+objects:
+  - {type: quad, corner: [-2, 0, -1], edge1: [4, 0, 0], edge2: [0, 2, 0], material: red}
+  - {type: quad, corner: [-2, 0, -1], edge1: [4, 0, 0], edge2: [0, 2, 0], material: green}
+  - {type: quad, corner: [-2, 0, -1], edge1: [4, 0, 0], edge2: [0, 2, 0], material: blue}
+  - {type: sphere, center: [0, 1, 0.5], radius: 0.6, material: red}
+  - {type: sphere, center: [0, 1, 0.5], radius: 0.6, material: mirror}
+  - {type: sphere, center: [0, 1, 0.5], radius: 0.6, material: green}
+  - {type: quad, corner: [-3, 0, -3], edge1: [6, 0, 0], edge2: [0, 0, 6], material: blue}
+  - {type: tri, v0: [-3, 0, 3], v1: [3, 0, 3], v2: [3, 0, -3], material: red}
+"""
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_exact_ties_resolve_like_the_reference(crt, oracle, mode):
+    """Coincident primitives give candidates with exactly equal t on every ray.  The reference's
+    ordered walk keeps the LAST visited triangle (closed interval, hittable.cuh:335) and the
+    FIRST visited sphere (open interval, :287-289); every geometry mode must pick the same one."""
+    sc = crt.parse_scene(TIES)
+    sc.set_mode(MODES[mode])
+    w, h = 64, 48
+    dp = _desc_ptr(crt, sc)
+    for sample in (1, 2):
+        g = sc.trace_primary(sample)
+        o = oracle_lib.trace_primary(oracle, dp, w, h, sample)
+        assert np.array_equal(g[0], o[0]), np.flatnonzero(g[0] != o[0])[:10]
+        assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
+    assert len(set(o[0].tolist()) - {-1}) >= 3                   # wall, sphere and floor all visible
+    buf = crt.create_buffer(sc)
+    ref = oracle_lib.new_passes(w, h)
+    oracle.oracle_set_pow5_mulchain(1)
+    try:
+        for done in range(2):
+            crt.render(sc, buf, samples=1, samples_done=done)
+            got = buf.download()
+            oracle_lib.render(oracle, dp, w, h, samples=1, samples_done=done, passes=ref)
+            for k in oracle_lib.PASSES:
+                a, b = got[k], ref[k]
+                assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (mode, k, done)
+    finally:
+        oracle.oracle_set_pow5_mulchain(0)
+    buf.close()
+    sc.close()
