@@ -7,7 +7,8 @@
 
 A step = one full render of the scene per GPU.  With N GPUs rank k renders sample numbers
 k*spp+1 .. (k+1)*spp of every pixel (weak scaling: per-GPU work is fixed, the image gets N*spp
-samples) and the ranks' means are combined by one RCCL all-reduce of the 14*W*H pass floats.
+samples) and the ranks' means are combined by one RCCL all-reduce of the 14*W*H pass floats,
+which runs while the next frame renders (every all-reduce completes inside the timed region).
 Inputs (scene in HBM, pass buffers allocated) are resident before the timed region; the timed
 region contains the render kernels, the resolve kernel and the all-reduce.
 
@@ -106,20 +107,46 @@ def main():
     ri = sc.render_info
     W, H, spp, bounces = ri.image_width, ri.image_height, ri.samples_per_pixel, ri.max_bounces
     sc.upload()
-    passes = torch.zeros(14 * W * H, dtype=torch.float32, device="cuda")
-    buf = crt.Buffer(W, H, ri.gamma, device_ptr=passes.data_ptr())
+    # Frames in flight: with more than one process the all-reduce of frame k runs while frame k+1
+    # (and the start of k+2) renders, so three sets of pass buffers rotate; a frame's buffers are
+    # rendered into again only after its all-reduce has finished.
+    depth = 3 if distributed else 1
+    passes = [torch.zeros(14 * W * H, dtype=torch.float32, device="cuda") for _ in range(depth)]
+    bufs = [crt.Buffer(W, H, ri.gamma, device_ptr=p.data_ptr()) for p in passes]
     lib = crt.lib()
     dev = sc.get_device_scene()
+    first, count = multi_gpu.rank_sample_range(rank, world, spp)
+    pending = [None] * depth
 
-    def step():
-        first, count = multi_gpu.rank_sample_range(rank, world, spp)
-        secs, rays = crt.render_range(sc, buf, first, count)
-        if distributed:
-            multi_gpu.combine_means(passes, count, spp * world, dist)
+    def wait_for(slot):
+        if pending[slot] is not None:
+            pending[slot].wait()
             torch.cuda.current_stream().synchronize()
-        tr, rs = C.c_float(0), C.c_float(0)
-        lib.crt_render_timings(dev, C.byref(tr), C.byref(rs))
-        return rays, tr.value, rs.value
+            pending[slot] = None
+
+    def run(steps):
+        """`steps` frames; returns (rays of this rank, summed kernel ms, summed resolve ms)."""
+        rays = 0
+        trace_ms = resolve_ms = 0.0
+        previous = None
+        for k in range(steps):
+            slot = k % depth
+            wait_for(slot)
+            crt.render_launch(sc, bufs[slot], first, count)
+            if previous is not None and distributed:
+                pending[previous] = multi_gpu.combine_means_async(passes[previous], count, spp * world, dist)
+            _, r = crt.render_finish(sc)
+            tr, rs = C.c_float(0), C.c_float(0)
+            lib.crt_render_timings(dev, C.byref(tr), C.byref(rs))
+            rays += r
+            trace_ms += tr.value
+            resolve_ms += rs.value
+            previous = slot
+        if previous is not None and distributed:
+            pending[previous] = multi_gpu.combine_means_async(passes[previous], count, spp * world, dist)
+        for slot in range(depth):
+            wait_for(slot)
+        return rays, trace_ms, resolve_ms
 
     def fence():
         torch.cuda.synchronize()
@@ -127,17 +154,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    rays_rank = 0
-    trace_ms = resolve_ms = 0.0
-    for _ in range(args.steps):
-        r, tr, rs = step()
-        rays_rank += r
-        trace_ms += tr
-        resolve_ms += rs
+    rays_rank, trace_ms, resolve_ms = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -173,7 +193,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, {spp} spp per GPU, {bounces} bounces",
-                       "sharding": "sample ranges per rank, one all-reduce of 14*W*H floats per frame" if world > 1 else "single GPU",
+                       "sharding": "sample ranges per rank, one all-reduce of 14*W*H floats per frame, overlapped with the next frame" if world > 1 else "single GPU",
                        "rays_per_step": rays_total // args.steps},
             "roofline": roofline,
         }
@@ -185,7 +205,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
 
-    buf.close()
+    for b in bufs:
+        b.close()
     sc.close()
     if distributed:
         dist.destroy_process_group()

@@ -314,6 +314,21 @@ def render_range(scene, buf, first_sample, samples):
     return secs.value, rays.value
 
 
+def render_launch(scene, buf, first_sample, samples):
+    """Starts render_range on the scene's stream without waiting (crt_render_launch)."""
+    _check(_lib.crt_render_launch(scene.get_device_scene(), buf.get_device_buffer(), first_sample, samples, 0))
+
+
+def render_finish(scene):
+    """Waits for the render started by render_launch; returns (kernel milliseconds, rays)."""
+    global last_ray_count
+    ms = C.c_float(0)
+    rays = C.c_uint64(0)
+    _check(_lib.crt_render_finish(scene.get_device_scene(), C.byref(ms), C.byref(rays)))
+    last_ray_count = rays.value
+    return ms.value, rays.value
+
+
 def bvh4_build(bbox_min, bbox_max, visible=None):
     """create_bvh4 (bvh.cuh:299-310) on padded object boxes; returns (min, max, children, object_index)."""
     mn = np.ascontiguousarray(bbox_min, np.float32)

@@ -37,3 +37,13 @@ def combine_means(passes, count, total, dist=None):
         passes.mul_(float(count) / float(total))
     dist.all_reduce(passes)
     return passes
+
+
+def combine_means_async(passes, count, total, dist):
+    """combine_means without waiting: returns the collective's work handle (None for a single
+    process).  The caller waits on it before the tensor is read or written again."""
+    if dist is None or not dist.is_initialized():
+        return None
+    if count != total:
+        passes.mul_(float(count) / float(total))
+    return dist.all_reduce(passes, async_op=True)

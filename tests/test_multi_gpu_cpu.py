@@ -55,7 +55,13 @@ def _worker(rank, world, port, size, spp, out_dir):
     first, count = multi_gpu.rank_sample_range(rank, world, spp)
     mean = _mean_of_range(crt, lib, sc, size, first, count)
     t = torch.from_numpy(mean.astype(np.float32))
+    t_async = t.clone()
     multi_gpu.combine_means(t, count, spp * world, dist)
+    # the overlapped form bench.py uses: start, do other work, wait
+    work = multi_gpu.combine_means_async(t_async, count, spp * world, dist)
+    assert work is not None
+    work.wait()
+    assert torch.equal(torch.nan_to_num(t), torch.nan_to_num(t_async))
     if rank == 0:
         np.save(os.path.join(out_dir, "combined.npy"), t.numpy())
     dist.destroy_process_group()
