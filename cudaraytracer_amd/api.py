@@ -164,6 +164,13 @@ class Scene:
             self._dev = h
         return self
 
+    def describe(self):
+        """Kernel variant of the next render: 'mode=flat slots=18 groups=2 reciprocal=newton ...'."""
+        self.upload()
+        buf = C.create_string_buffer(256)
+        _check(_lib.crt_scene_describe(self._dev, buf, 256))
+        return buf.value.decode()
+
     def set_mode(self, mode):
         """Geometry access path: 0 automatic, 1 BVH4 walk in HBM, 2 BVH4 walk in LDS, 3 flat slots."""
         self.upload()

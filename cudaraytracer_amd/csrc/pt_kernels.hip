@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1011,6 +1012,18 @@ int crt_scene_set_mode(crt_scene* sc, int mode) {
     if (mode < 0 || mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_set_mode: mode must be 0..3");
     sc->mode = mode;
     return CRT_OK;
+}
+
+int crt_scene_describe(crt_scene* sc, char* text, int size) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
+    static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
+    char line[256];
+    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d", names[kernel_mode(sc)],
+                                sc->flat.slot_count, sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
+                                sc->dev.node_count, sc->dev.object_count);
+    if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);
+    return n;
 }
 
 void* crt_scene_stream(crt_scene* sc) { return sc ? (void*)sc->stream : nullptr; }

@@ -238,6 +238,11 @@ int crt_profile_counters(uint64_t* out64, int reset);
  * back to the next one.  All modes produce the same image. */
 int crt_scene_set_mode(crt_scene* sc, int mode);
 
+/* Which kernel variant the next render of this scene uses, as text for logs and tests, e.g.
+ * "mode=flat slots=18 groups=2 reciprocal=newton stack=8+0 nodes=21 objects=36".
+ * Writes at most `size` bytes including the terminator; returns the full length. */
+int crt_scene_describe(crt_scene* sc, char* text, int size);
+
 /* Primary-ray probe used by the parity tests: for every pixel trace the camera ray of
  * sample number `sample` (1-based, as in render.cuh:128) and return the closest hit of
  * bounce 0: object index (-1 = miss), ray parameter t, surface u, v, front_face.

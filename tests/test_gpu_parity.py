@@ -351,3 +351,26 @@ def test_exact_ties_resolve_like_the_reference(crt, oracle, mode):
         oracle.oracle_set_pow5_mulchain(0)
     buf.close()
     sc.close()
+
+
+def test_kernel_variant_selection(crt):
+    """Automatic choice of the geometry path and of the reciprocal form per scene."""
+    def describe(name, **kw):
+        sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
+        if kw:
+            sc.set_render(**kw)
+        text = dict(item.split("=") for item in sc.describe().split())
+        sc.close()
+        return text
+    d = describe("cornell_box.yaml", width=64, height=64)
+    assert (d["mode"], d["slots"], d["groups"], d["reciprocal"]) == ("flat", "18", "2", "newton")
+    d = describe("orthographic.yaml")
+    assert d["mode"] == "flat" and d["groups"] == "0"
+    d = describe("features_tree.yaml")
+    assert d["mode"] in ("tree_lds", "tree_hbm") and d["objects"] == "166"
+    d = describe("obj.yaml", width=64, height=64)
+    assert d["mode"] == "tree_hbm" and d["stack"] == "16+0" and d["objects"] == "976"
+    # a fuzz beyond the range the bound proof covers falls back to IEEE division
+    sc = crt.parse_scene(TIES.replace("type: metal, color: [0.9, 0.9, 0.9]", "type: metal, color: [0.9, 0.9, 0.9], fuzz: 1.0e35"))
+    assert "reciprocal=ieee" in sc.describe()
+    sc.close()
