@@ -20,6 +20,17 @@ void clear_error();
 int build_bvh4(const std::vector<Box>& boxes, const std::vector<uint8_t>& visible, std::vector<float>& min_bounds,
                std::vector<float>& max_bounds, std::vector<int32_t>& children, std::vector<int32_t>& object_index);
 
+// One node of the hierarchy the device walks: four slots, each empty (box +inf/-inf, both
+// indices -1), a primitive (object >= 0) or an inner child (child >= 0).
+struct AccelNode {
+    float lo[4][3], hi[4][3];
+    int32_t child[4], object[4];
+};
+// Surface-area-heuristic hierarchy over the leaf slots (boxes and objects) of a reference BVH4.
+void build_accel(const crt_bvh4& ref, std::vector<AccelNode>& nodes, int& depth);
+// The reference BVH4 itself in that form.
+void accel_from_reference(const crt_bvh4& ref, std::vector<AccelNode>& nodes);
+
 // Image decoding for `type: image` textures. Returns true on success; pixels has
 // width*height*channels bytes, channels in {1,3,4}.
 bool load_image_file(const std::string& path, float hdr_gamma, float hdr_scale, int desired_channels, bool flip_y,

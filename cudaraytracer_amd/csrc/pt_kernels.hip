@@ -665,12 +665,6 @@ bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
     return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p90 && edges * dir_object < 0x1p99;
 }
 
-bool node_is_leafy(const crt_bvh4& b, int node) {
-    for (int i = 0; i < 4; i++)
-        if (b.object_index[node * 4 + i] >= 0) return true;
-    return false;
-}
-
 // Leaf slots in the order the reference's traversal visits them when every box is hit
 // (bvh.cuh:387-419): slots 0..3 of a node in order, pushed children popped last-in first-out.
 void reference_visit_order(const crt_bvh4& b, std::vector<int>& leaf_slots) {
@@ -713,26 +707,38 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     int bvh_depth = 0;
     std::string why;
     if (validate(d, bvh_depth, why) != CRT_OK) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: " + why);
+    // The hierarchy the tree modes walk: built here over the reference tree's leaf slots (see
+    // accel_build.cpp); CRT_ACCEL=reference walks the reference tree itself.
+    std::vector<AccelNode> accel;
+    int accel_depth = bvh_depth;
+    const char* accel_env = std::getenv("CRT_ACCEL");
+    if (accel_env && std::string(accel_env) == "reference") accel_from_reference(d->bvh, accel);
+    else build_accel(d->bvh, accel, accel_depth);
     // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
-    const int need = 3 * (bvh_depth - 1) + 1;
-    if (need > 256) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: BVH deeper than 86 levels");
+    const int need = 3 * (accel_depth - 1) + 1;
+    if (need > 1024) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: hierarchy deeper than 342 levels");
     const int stack_entries = need <= 8 ? 8 : 16;
 
-    const int nodes = d->bvh.slot_count / 4;
+    const int nodes = (int)accel.size();
+    auto accel_leafy = [&](int node) {
+        for (int i = 0; i < 4; i++)
+            if (accel[(size_t)node].object[i] >= 0) return true;
+        return false;
+    };
     // ---- repack: nodes (node-major, 8 float4), prims, shade, xforms (deduplicated), mats, texs
     std::vector<float> node_rec((size_t)nodes * kNodeStrideGlobal * 4, 0.0f);
     for (int n = 0; n < nodes; n++) {
         float* rec = &node_rec[(size_t)n * kNodeStrideGlobal * 4];
+        const AccelNode& an = accel[(size_t)n];
         for (int i = 0; i < 4; i++) {
-            int s = n * 4 + i;
             for (int a = 0; a < 3; a++) {
-                rec[(a)*4 + i] = d->bvh.min_bounds[3 * s + a];
-                rec[(3 + a) * 4 + i] = d->bvh.max_bounds[3 * s + a];
+                rec[(a)*4 + i] = an.lo[i][a];
+                rec[(3 + a) * 4 + i] = an.hi[i][a];
             }
-            int o = d->bvh.object_index[s], c = d->bvh.children[s];
+            const int o = an.object[i], c = an.child[i];
             // slot code: object index, or -(2*child + leafy) - 2 for an internal slot, or -1 (empty);
             // leafy = the child node has leaf slots of its own
-            int32_t code = o >= 0 ? o : (c >= 0 ? -(2 * c + (node_is_leafy(d->bvh, c) ? 1 : 0)) - 2 : -1);
+            int32_t code = o >= 0 ? o : (c >= 0 ? -(2 * c + (accel_leafy(c) ? 1 : 0)) - 2 : -1);
             rec[6 * 4 + i] = as_float(code);
         }
         // Visiting order of the four slots for each of the 8 direction octants (bit 0/1/2 set:
@@ -743,10 +749,9 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
             float key[4];
             int idx[4] = {0, 1, 2, 3};
             for (int i = 0; i < 4; i++) {
-                const int s = n * 4 + i;
                 float k = 0.0f;
                 for (int a = 0; a < 3; a++) {
-                    const float c = 0.5f * (d->bvh.min_bounds[3 * s + a] + d->bvh.max_bounds[3 * s + a]);
+                    const float c = 0.5f * (an.lo[i][a] + an.hi[i][a]);
                     k += ((oct >> a) & 1) ? -c : c;
                 }
                 key[i] = std::isfinite(k) ? k : INFINITY;            // empty slots last
@@ -971,7 +976,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     D.width = d->render.image_width;
     D.height = d->render.image_height;
     D.max_bounces = d->render.max_bounces;
-    D.root_entry = node_is_leafy(d->bvh, 0) ? 1 : 0;
+    D.root_entry = accel_leafy(0) ? 1 : 0;
     D.fast_rcp = fast_reciprocal_is_exact(d) ? 1 : 0;
     if (const char* e = std::getenv("CRT_FAST_RCP")) D.fast_rcp = std::atoi(e) ? D.fast_rcp : 0;   // 0 forces IEEE division
     const crt_camera& c = d->camera;
