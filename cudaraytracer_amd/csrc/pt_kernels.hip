@@ -1129,7 +1129,7 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     A.spill_threads = sc->spill_threads;
     A.prim_batch = 8;
     if (const char* e = std::getenv("CRT_PRIM_BATCH")) A.prim_batch = std::min(64, std::max(1, std::atoi(e)));
-    A.ready_percent = 50;
+    A.ready_percent = 65;
     if (const char* e = std::getenv("CRT_READY_PERCENT")) A.ready_percent = std::min(100, std::max(1, std::atoi(e)));
     A.ray_counter = sc->ray_counter;
     A.queue = reinterpret_cast<unsigned int*>(sc->ray_counter + 1);
