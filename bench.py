@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 # Algorithmic work per ray under the reference traversal order (survey constants):
 #   flops/ray F = 24*N_box + 84*N_prim + 60*N_accept + 100, bytes/ray B = 128 (path state + hit record)
-FLOPS_PER_RAY = {"cornell_box.yaml": 1116.0, "orthographic.yaml": 485.0}
+FLOPS_PER_RAY = {"cornell_box.yaml": 1116.0, "orthographic.yaml": 485.0, "obj.yaml": 1488.0}
 BYTES_PER_RAY = 128.0
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 peak
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak
@@ -188,7 +188,8 @@ def main():
                         "hbm": {"achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round(hbm / PEAK_HBM_GBS, 4), "bytes_per_ray": BYTES_PER_RAY}}
         out = {
-            "metric": "Mrays/s (whole node) Cornell box 1000x1000, 50spp, 15 bounces",
+            "metric": "Mrays/s (whole node) Cornell box 1000x1000, 50spp, 15 bounces" if args.scene == "cornell_box.yaml"
+                      else f"Mrays/s (whole node) {args.scene}",
             "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
