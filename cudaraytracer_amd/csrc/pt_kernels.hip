@@ -715,7 +715,14 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     if (accel_env && std::string(accel_env) == "reference") accel_from_reference(d->bvh, accel);
     else build_accel(d->bvh, accel, accel_depth);
     // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
-    const int need = 3 * (accel_depth - 1) + 1;
+    int need = 3 * (accel_depth - 1) + 1;
+    if (need > 1024) {
+        // a pathologically unbalanced surface-area split (sizes in a geometric series): the
+        // reference's median split is balanced by construction, walk that instead
+        accel_from_reference(d->bvh, accel);
+        accel_depth = bvh_depth;
+        need = 3 * (accel_depth - 1) + 1;
+    }
     if (need > 1024) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: hierarchy deeper than 342 levels");
     const int stack_entries = need <= 8 ? 8 : 16;
 
