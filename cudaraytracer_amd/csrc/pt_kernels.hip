@@ -463,6 +463,7 @@ struct crt_scene {
     bool can_lds = false, can_flat = false;
     FlatView flat = {};
     int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
+    bool ordered = false;            // walked in the reference's order (a primitive sticks out of its box)
     float* partial = nullptr;
     size_t partial_bytes = 0;
     unsigned long long* ray_counter = nullptr;
@@ -681,6 +682,49 @@ void reference_visit_order(const crt_bvh4& b, std::vector<int>& leaf_slots) {
     }
 }
 
+// Does every primitive lie inside the box of its own leaf slot?  The reference shrinks the ray
+// interval to the closest hit so far while it walks (bvh.cuh:398,407-411), so a primitive is
+// only tested if its leaf box is still hit at that moment.  When every box contains its
+// primitive, the closest hit comes out the same whatever the order of the walk.  When one does
+// not, it depends on the reference's own order.  That happens: hittable::translate also moves
+// the rotation anchor, and hittable::rotate replaces an earlier rotation and re-adds the
+// translation to an already translated box (hittable.cuh:77-127 against :429), so a translate
+// wrapped around a rotate, or nested rotates, leave the box and the tested geometry apart.
+// Such a scene is walked in the reference's order over the reference's tree.
+bool primitives_inside_their_boxes(const crt_scene_desc* d) {
+    for (int s = 0; s < d->bvh.slot_count; s++) {
+        const int oi = d->bvh.object_index[s];
+        if (oi < 0) continue;
+        const crt_object& o = d->objects[oi];
+        const float* lo = &d->bvh.min_bounds[3 * s];
+        const float* hi = &d->bvh.max_bounds[3 * s];
+        float scale = 1.0f;
+        for (int a = 0; a < 3; a++) scale = std::fmax(scale, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+        const float tol = 1e-5f * scale;
+        const bool moved = !(identity9(o.rotation) && identity9(o.rotation_inv) && zero3(o.anchor) && zero3(o.translation));
+        auto inside = [&](const float p[3], float radius) {
+            float w[3] = {p[0], p[1], p[2]};
+            if (moved) {                                            // inverse of the ray transform at hittable.cuh:429
+                const float q[3] = {p[0] - o.anchor[0], p[1] - o.anchor[1], p[2] - o.anchor[2]};
+                for (int r = 0; r < 3; r++)
+                    w[r] = o.rotation[3 * r] * q[0] + o.rotation[3 * r + 1] * q[1] + o.rotation[3 * r + 2] * q[2] + o.anchor[r] + o.translation[r];
+            }
+            for (int a = 0; a < 3; a++)
+                if (!(w[a] - radius >= lo[a] - tol && w[a] + radius <= hi[a] + tol)) return false;
+            return true;
+        };
+        const float second[3] = {o.p0[0] + o.p1[0], o.p0[1] + o.p1[1], o.p0[2] + o.p1[2]};   // vertex 1 / centre at time 1
+        if (o.type == CRT_OBJ_TRI) {
+            const float third[3] = {o.p0[0] + o.p2[0], o.p0[1] + o.p2[1], o.p0[2] + o.p2[2]};
+            if (!inside(o.p0, 0.0f) || !inside(second, 0.0f) || !inside(third, 0.0f)) return false;
+        } else {
+            const float radius = std::fabs(o.p2[0]);
+            if (!inside(o.p0, radius) || !inside(second, radius)) return false;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -711,8 +755,10 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     // accel_build.cpp); CRT_ACCEL=reference walks the reference tree itself.
     std::vector<AccelNode> accel;
     int accel_depth = bvh_depth;
-    const char* accel_env = std::getenv("CRT_ACCEL");
-    if (accel_env && std::string(accel_env) == "reference") accel_from_reference(d->bvh, accel);
+    // CRT_ACCEL=ordered: the reference's tree in the reference's order, whatever the scene.
+    const std::string accel_env = std::getenv("CRT_ACCEL") ? std::getenv("CRT_ACCEL") : "";
+    const bool ordered = accel_env == "ordered" || !primitives_inside_their_boxes(d);
+    if (ordered || accel_env == "reference") accel_from_reference(d->bvh, accel);
     else build_accel(d->bvh, accel, accel_depth);
     // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
     int need = 3 * (accel_depth - 1) + 1;
@@ -751,8 +797,11 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         // Visiting order of the four slots for each of the 8 direction octants (bit 0/1/2 set:
         // the ray runs towards -x/-y/-z): slots sorted by their box centre along the octant's
         // diagonal, nearest first; 2 bits per slot, one byte per octant.
+        // A scene that has to be walked in the reference's order (bvh.cuh:391-418: children pushed
+        // in slot order, popped last-in first-out) gets "3,2,1,0" for every octant.
         uint32_t words[2] = {0, 0};
-        for (int oct = 0; oct < 8; oct++) {
+        if (ordered) words[0] = words[1] = 0x1b1b1b1bu;
+        for (int oct = 0; oct < 8 && !ordered; oct++) {
             float key[4];
             int idx[4] = {0, 1, 2, 3};
             for (int i = 0; i < 4; i++) {
@@ -840,7 +889,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     std::vector<float> flat_box_rec, flat_slot_rec, flat_group_xf;
     std::vector<int32_t> flat_ent_obj;
     int flat_groups = 0, flat_group_end[kMaxFlatGroups + 1] = {0, 0, 0};
-    bool can_flat = !leaf_slots.empty() && leaf_slots.size() <= 64;
+    bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
     if (can_flat) {
         struct Slot {
             int group, xf, type, rank_a, rank_b;
@@ -1003,6 +1052,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
     sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
     sc->can_flat = can_flat;
+    sc->ordered = ordered;
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
     sc->flat.ent_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
@@ -1031,9 +1081,9 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d", names[kernel_mode(sc)],
+    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s", names[kernel_mode(sc)],
                                 sc->flat.slot_count, sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
-                                sc->dev.node_count, sc->dev.object_count);
+                                sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free");
     if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);
     return n;
 }

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -492,6 +493,7 @@ struct ray_info {
     vec3 col, albedo, emission, normal;
     float depth, opacity;
 };
+static thread_local bool g_trace_path = false;
 void get_ray_info(const crt_scene_desc* sc, const ray& r, rng_state& rs, ray_info& result, counters& cnt) {
     ray cur_ray = r;
     vec3 cur_attenuation(1, 1, 1);
@@ -499,7 +501,13 @@ void get_ray_info(const crt_scene_desc* sc, const ray& r, rng_state& rs, ray_inf
     int bounces = 0;
     int max_bounces = sc->render.max_bounces;
     while (bounces < max_bounces) {
-        if (bvh4_hit(sc, cur_ray, interval(0.001f, k_inf), rec, cnt)) {
+        const bool any_hit = bvh4_hit(sc, cur_ray, interval(0.001f, k_inf), rec, cnt);
+        if (g_trace_path) {             // development aid: ORACLE_TRACE_PIXEL=<pixel index> prints the path
+            std::printf("  bounce %d  o %.9g %.9g %.9g  d %.9g %.9g %.9g  time %.9g  hit %d t %.9g object %d\n", bounces,
+                        cur_ray.orig.x(), cur_ray.orig.y(), cur_ray.orig.z(), cur_ray.dir.x(), cur_ray.dir.y(), cur_ray.dir.z(),
+                        cur_ray.tm, (int)any_hit, any_hit ? rec.t : 0.0f, any_hit ? rec.obj_idx : -1);
+        }
+        if (any_hit) {
             ray scattered;
             vec3 attenuation;
             if (scatter(sc, cur_ray, rec, attenuation, scattered, rs)) {
@@ -562,7 +570,11 @@ void render_pixel(const crt_scene_desc* sc, int i, int j, int samples, int sampl
         ray_info result;
         result.depth = 0.0f; result.opacity = 0.0f;   // uninitialised in the reference; always written when max_bounces >= 1
         ray r = get_ray(sc->camera, i, j, rs);
+        static const char* trace_env = std::getenv("ORACLE_TRACE_PIXEL");
+        g_trace_path = trace_env && std::atoi(trace_env) == pixel_index;
+        if (g_trace_path) std::printf("pixel %d sample %d\n", pixel_index, current_sample);
         get_ray_info(sc, r, rs, result, cnt);
+        g_trace_path = false;
         if (current_sample == 1) {
             *C = result.col; *A = result.albedo; *E = result.emission; *N = result.normal;
             depth[pixel_index] = result.depth; opacity[pixel_index] = result.opacity;

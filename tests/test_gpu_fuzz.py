@@ -1,0 +1,137 @@
+"""Seeded random scenes: every object type, wrapper and material the scene format has, in random
+numbers and places, rendered by the HIP path in each geometry mode and by the CPU oracle.  All six
+passes and the ray count must be equal bit for bit, sample after sample.  Wrappers are nested at
+random too, which includes the combinations whose boxes do not contain their geometry.
+
+Left out on purpose: image textures and normal maps on spheres and environment images, whose
+texture coordinates go through acosf/atan2f (device and host libm differ in the last bit there;
+those have tolerance tests of their own)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+# "ordered": the reference's tree walked in the reference's order even where the library would
+# have chosen a hierarchy and an order of its own
+MODES = {"auto": 0, "tree_hbm": 1, "tree_lds": 2, "ordered": 1}
+
+
+def _vec(rng, lo, hi):
+    return "[%s]" % ", ".join("%.4f" % rng.uniform(lo, hi) for _ in range(3))
+
+
+def _texture(rng, depth=0):
+    if depth == 0 and rng.random() < 0.3:
+        return "{type: checker, scale: %.3f, odd: %s, even: %s}" % (rng.uniform(0.2, 1.5), _texture(rng, 1), _texture(rng, 1))
+    return "{type: solid_color, color: %s}" % _vec(rng, 0.05, 0.95)
+
+
+def _material(rng):
+    kind = rng.random()
+    if kind < 0.45:
+        return "{type: lambertian, texture: %s}" % _texture(rng)
+    if kind < 0.7:
+        fuzz = rng.choice([0.0, rng.uniform(0.05, 0.9)])
+        return "{type: metal, color: %s, fuzz: %.3f}" % (_vec(rng, 0.3, 1.0), fuzz)
+    if kind < 0.85:
+        return "{type: dielectric, ior: %.3f}" % rng.uniform(1.1, 2.2)
+    return "{type: diffuse_light, texture: {type: solid_color, color: %s}}" % _vec(rng, 0.5, 6.0)
+
+
+def _object(rng, extent, wrappers, depth=0):
+    kind = rng.random()
+    if depth < wrappers and kind < 0.2:
+        inner = _object(rng, extent, wrappers, depth + 1)
+        if rng.random() < 0.5:
+            return "{type: translate, offset: %s, object: %s}" % (_vec(rng, -1.0, 1.0), inner)
+        anchor = ", anchor: %s" % _vec(rng, -extent, extent) if rng.random() < 0.3 else ""
+        return "{type: rotate, angles: %s%s, object: %s}" % (_vec(rng, -80.0, 80.0), anchor, inner)
+    mat = _material(rng)
+    if kind < 0.45:
+        c = _vec(rng, -extent, extent)
+        moving = ", center2: %s" % _vec(rng, -extent, extent) if rng.random() < 0.25 else ""
+        return "{type: sphere, center: %s%s, radius: %.4f, material: %s}" % (c, moving, rng.uniform(0.1, 0.9), mat)
+    if kind < 0.6:
+        return "{type: tri, v0: %s, v1: %s, v2: %s, material: %s}" % (_vec(rng, -extent, extent), _vec(rng, -extent, extent), _vec(rng, -extent, extent), mat)
+    if kind < 0.78:
+        return "{type: quad, corner: %s, edge1: %s, edge2: %s, material: %s}" % (_vec(rng, -extent, extent), _vec(rng, -2.0, 2.0), _vec(rng, -2.0, 2.0), mat)
+    if kind < 0.93:
+        c1 = [rng.uniform(-extent, extent) for _ in range(3)]
+        c2 = [v + rng.uniform(0.2, 1.5) for v in c1]
+        return "{type: box, corner1: [%.4f, %.4f, %.4f], corner2: [%.4f, %.4f, %.4f], material: %s}" % (*c1, *c2, mat)
+    smooth = "true" if rng.random() < 0.5 else "false"
+    return "{type: uv_sphere, center: %s, radius: %.4f, rings: %d, segments: %d, shade_smooth: %s, material: %s}" % (
+        _vec(rng, -extent, extent), rng.uniform(0.3, 1.0), rng.randint(3, 6), rng.randint(4, 9), smooth, mat)
+
+
+def random_scene(seed, count):
+    rng = random.Random(seed)
+    wrappers = 1 + seed % 2          # odd seeds nest wrappers, even seeds keep boxes and geometry together
+    extent = 2.0 + 0.15 * count ** 0.5
+    if rng.random() < 0.7:
+        defocus = ", defocus_angle: %.3f, focus_dist: %.3f" % (rng.uniform(0.2, 2.0), rng.uniform(4.0, 12.0)) if rng.random() < 0.5 else ""
+        camera = "{type: perspective, from: %s, to: %s, vfov: %.2f%s}" % (_vec(rng, 5.0, 9.0), _vec(rng, -0.5, 0.5), rng.uniform(25.0, 70.0), defocus)
+    else:
+        camera = "{type: orthographic, from: %s, to: %s, width: %.3f}" % (_vec(rng, 5.0, 9.0), _vec(rng, -0.5, 0.5), rng.uniform(4.0, 10.0))
+    lines = ["camera: " + camera,
+             "render: {width: 48, height: 32, samples: 3, max_bounces: %d}" % rng.randint(2, 9),
+             "environment:",
+             "  texture: {type: solid_color, color: %s}" % _vec(rng, 0.0, 1.0),
+             "objects:"]
+    for _ in range(count):
+        lines.append("  - " + _object(rng, extent, wrappers))
+    return "\n".join(lines) + "\n"
+
+
+CASES = [(seed, count) for seed, count in zip(range(101, 117), (1, 3, 6, 6, 9, 14, 20, 20, 33, 48, 75, 75, 120, 260, 700, 700))]
+# CRT_FUZZ_EXTRA=n adds n more scenes (a longer hunt than the default run needs)
+_COUNTS = (2, 2, 5, 8, 8, 12, 18, 18, 27, 40, 40, 60, 90, 90, 150, 300, 300, 500, 500)
+CASES += [(1000 + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.get("CRT_FUZZ_EXTRA", "0")))]
+
+
+@pytest.mark.parametrize("seed,count", CASES)
+def test_random_scene_bit_exact_in_every_mode(crt, oracle, seed, count):
+    from cudaraytracer_amd import api
+    text = random_scene(seed, count)
+    w, h = 48, 32
+    oracle.oracle_set_pow5_mulchain(1)          # (1-cos)^5 as the device computes it: four multiplications
+    try:
+        reference = None
+        for mode in MODES:
+            sc = crt.parse_scene(text)
+            if mode == "ordered":
+                os.environ["CRT_ACCEL"] = "ordered"
+            try:
+                sc.set_mode(MODES[mode])        # uploads the scene
+            finally:
+                os.environ.pop("CRT_ACCEL", None)
+            assert mode != "ordered" or "order=reference" in sc.describe()
+            assert seed % 2 or mode == "ordered" or "order=free" in sc.describe()
+            dp = crt.lib().crt_host_scene_desc(sc._host)
+            if reference is None:
+                reference = []
+                ref = oracle_lib.new_passes(w, h)
+                for done in range(3):
+                    _, stats = oracle_lib.render(oracle, dp, w, h, samples=1, samples_done=done, passes=ref)
+                    reference.append(({k: v.copy() for k, v in ref.items()}, stats["rays"]))
+            buf = crt.create_buffer(sc)
+            for done in range(3):
+                crt.render(sc, buf, samples=1, samples_done=done)
+                got = buf.download()
+                want, rays = reference[done]
+                assert api.last_ray_count == rays, f"seed {seed} {mode}: ray count after sample {done + 1}"
+                for k in oracle_lib.PASSES:
+                    a, b = got[k], want[k]
+                    same = (a == b) | (np.isnan(a) & np.isnan(b))
+                    assert same.all(), f"seed {seed} ({sc.describe()}) {mode}: pass {k} differs after sample {done + 1}: {np.flatnonzero(~same)[:8]}"
+            buf.close()
+            sc.close()
+        assert reference is not None
+    finally:
+        oracle.oracle_set_pow5_mulchain(0)
+

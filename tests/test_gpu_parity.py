@@ -193,11 +193,14 @@ def test_environment_image_scene_matches_oracle(crt, oracle):
 
 @pytest.mark.parametrize("name,mode", [("features_small.yaml", "auto"), ("features_small.yaml", "tree_lds"),
                                        ("features_small.yaml", "tree_hbm"), ("features_tree.yaml", "auto"),
-                                       ("features_tree.yaml", "tree_hbm")])
+                                       ("features_tree.yaml", "tree_hbm"), ("nested_wrappers.yaml", "auto"),
+                                       ("nested_wrappers.yaml", "tree_hbm")])
 def test_feature_scenes_bit_exact(crt, oracle, name, mode):
     """Defocus camera, moving sphere, glass, fuzzy metal, checker, image texture + normal map on a
-    quad, rotated box, translated + rotated sphere, smooth-shaded UV sphere, coloured environment:
-    every pass equal to the oracle's, sample by sample, in every geometry mode."""
+    quad, rotated box, translated sphere, rotated sphere, smooth-shaded UV sphere, coloured
+    environment; and a scene of wrappers inside wrappers, whose boxes do not contain their geometry
+    and whose image therefore depends on the reference's walking order: every pass equal to the
+    oracle's, sample by sample, in every geometry mode."""
     sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
     w, h = 96, 64
     sc.set_mode(MODES[mode])
@@ -366,8 +369,14 @@ def test_kernel_variant_selection(crt):
     assert (d["mode"], d["slots"], d["groups"], d["reciprocal"]) == ("flat", "18", "2", "newton")
     d = describe("orthographic.yaml")
     assert d["mode"] == "flat" and d["groups"] == "0"
+    d = describe("features_small.yaml")
+    assert d["mode"] == "flat" and d["order"] == "free"
     d = describe("features_tree.yaml")
-    assert d["mode"] in ("tree_lds", "tree_hbm") and d["objects"] == "166"
+    assert d["mode"] in ("tree_lds", "tree_hbm") and d["objects"] == "167" and d["order"] == "free"
+    # wrappers inside wrappers leave boxes and geometry apart (hittable.cuh:77-127 against :429): such
+    # a scene is walked in the reference's order over the reference's tree, never by the flat mode
+    d = describe("nested_wrappers.yaml")
+    assert d["mode"] in ("tree_lds", "tree_hbm") and d["order"] == "reference"
     d = describe("obj.yaml", width=64, height=64)
     assert d["mode"] == "tree_hbm" and d["stack"].startswith("16+") and d["objects"] == "976"
     # a fuzz beyond the range the bound proof covers falls back to IEEE division

@@ -1,0 +1,37 @@
+"""Development helper: which pixels of a random test scene differ from the oracle, per mode/env."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import cudaraytracer_amd as crt
+from cudaraytracer_amd import api
+import oracle_lib, test_gpu_fuzz as f
+
+seed, count = int(sys.argv[1]), int(sys.argv[2])
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+o = oracle_lib.load()
+o.oracle_set_pow5_mulchain(1)
+text = f.random_scene(seed, count)
+sc = crt.parse_scene(text)
+sc.set_mode(mode)
+print(sc.describe(), "env", {k: v for k, v in os.environ.items() if k.startswith("CRT_")})
+dp = crt.lib().crt_host_scene_desc(sc._host)
+w, h = 48, 32
+for sample in range(1, 4):
+    g = sc.trace_primary(sample)
+    r = oracle_lib.trace_primary(o, dp, w, h, sample)
+    bad = np.flatnonzero((g[0] != r[0]) | (g[1].view(np.uint32) != r[1].view(np.uint32)))
+    print("primary sample", sample, "diff", bad[:10], [(g[0][i], r[0][i], g[1][i], r[1][i]) for i in bad[:4]])
+buf = crt.create_buffer(sc)
+ref = oracle_lib.new_passes(w, h)
+for done in range(3):
+    crt.render(sc, buf, samples=1, samples_done=done)
+    got = buf.download()
+    _, st = oracle_lib.render(o, dp, w, h, samples=1, samples_done=done, passes=ref)
+    print("sample", done, "rays", api.last_ray_count, st["rays"])
+    for k in oracle_lib.PASSES:
+        a, b = got[k], ref[k]
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if not same.all():
+            idx = np.flatnonzero(~same.reshape(w * h, -1).all(axis=1))
+            print("  pass", k, "pixels", idx[:10], "got", a.reshape(w * h, -1)[idx[0]], "want", b.reshape(w * h, -1)[idx[0]])
