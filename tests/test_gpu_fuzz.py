@@ -21,6 +21,9 @@ pytestmark = pytest.mark.gpu
 MODES = {"auto": 0, "tree_hbm": 1, "tree_lds": 2, "ordered": 1}
 
 
+_SCALE = int(os.environ.get("CRT_FUZZ_SCALE", "1"))
+
+
 def _vec(rng, lo, hi):
     return "[%s]" % ", ".join("%.4f" % rng.uniform(lo, hi) for _ in range(3))
 
@@ -52,6 +55,18 @@ def _object(rng, extent, wrappers, depth=0):
         anchor = ", anchor: %s" % _vec(rng, -extent, extent) if rng.random() < 0.3 else ""
         return "{type: rotate, angles: %s%s, object: %s}" % (_vec(rng, -80.0, 80.0), anchor, inner)
     mat = _material(rng)
+    if rng.random() < 0.04:             # degenerate shapes: no area, no volume, huge, far away
+        pick = rng.randrange(5)
+        p = _vec(rng, -extent, extent)
+        if pick == 0:
+            return "{type: tri, v0: %s, v1: %s, v2: %s, material: %s}" % (p, p, _vec(rng, -extent, extent), mat)
+        if pick == 1:
+            return "{type: sphere, center: %s, radius: 0, material: %s}" % (p, mat)
+        if pick == 2:
+            return "{type: quad, corner: %s, edge1: [1.5, 0.5, 0], edge2: [3, 1, 0], material: %s}" % (p, mat)
+        if pick == 3:
+            return "{type: sphere, center: [0, -1000, 0], radius: %.3f, material: %s}" % (1000 - extent - rng.uniform(0.0, 1.0), mat)
+        return "{type: box, corner1: [1.0e6, 1.0e6, 1.0e6], corner2: [1.0e6, 1.0e6, 1.00001e6], material: %s}" % mat
     if kind < 0.45:
         c = _vec(rng, -extent, extent)
         moving = ", center2: %s" % _vec(rng, -extent, extent) if rng.random() < 0.25 else ""
@@ -79,7 +94,7 @@ def random_scene(seed, count):
     else:
         camera = "{type: orthographic, from: %s, to: %s, width: %.3f}" % (_vec(rng, 5.0, 9.0), _vec(rng, -0.5, 0.5), rng.uniform(4.0, 10.0))
     lines = ["camera: " + camera,
-             "render: {width: 48, height: 32, samples: 3, max_bounces: %d}" % rng.randint(2, 9),
+             "render: {width: %d, height: %d, samples: 3, max_bounces: %d}" % (_SCALE * rng.randint(9, 70), _SCALE * rng.randint(5, 45), rng.choice([1, 2, 3, 4, 6, 9, 30])),
              "environment:",
              "  texture: {type: solid_color, color: %s}" % _vec(rng, 0.0, 1.0),
              "objects:"]
@@ -89,7 +104,8 @@ def random_scene(seed, count):
 
 
 CASES = [(seed, count) for seed, count in zip(range(101, 117), (1, 3, 6, 6, 9, 14, 20, 20, 33, 48, 75, 75, 120, 260, 700, 700))]
-# CRT_FUZZ_EXTRA=n adds n more scenes (a longer hunt than the default run needs)
+# CRT_FUZZ_EXTRA=n adds n more scenes, CRT_FUZZ_SCALE=k renders them k times as wide and high
+# (a longer hunt than the default run needs)
 _COUNTS = (2, 2, 5, 8, 8, 12, 18, 18, 27, 40, 40, 60, 90, 90, 150, 300, 300, 500, 500)
 CASES += [(1000 + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.get("CRT_FUZZ_EXTRA", "0")))]
 
@@ -98,7 +114,6 @@ CASES += [(1000 + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.ge
 def test_random_scene_bit_exact_in_every_mode(crt, oracle, seed, count):
     from cudaraytracer_amd import api
     text = random_scene(seed, count)
-    w, h = 48, 32
     oracle.oracle_set_pow5_mulchain(1)          # (1-cos)^5 as the device computes it: four multiplications
     try:
         reference = None
@@ -113,6 +128,7 @@ def test_random_scene_bit_exact_in_every_mode(crt, oracle, seed, count):
             assert mode != "ordered" or "order=reference" in sc.describe()
             assert seed % 2 or mode == "ordered" or "order=free" in sc.describe()
             dp = crt.lib().crt_host_scene_desc(sc._host)
+            w, h = sc.desc.render.image_width, sc.desc.render.image_height
             if reference is None:
                 reference = []
                 ref = oracle_lib.new_passes(w, h)
