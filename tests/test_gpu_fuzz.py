@@ -3,7 +3,8 @@ numbers and places, rendered by the HIP path in each geometry mode and by the CP
 passes and the ray count must be equal bit for bit, sample after sample.  Wrappers are nested at
 random too, which includes the combinations whose boxes do not contain their geometry.
 
-Left out on purpose: image textures and normal maps on spheres and environment images, whose
+Image textures and normal maps sit on triangles only.  Left out on purpose: image textures and
+normal maps on spheres and environment images, whose
 texture coordinates go through acosf/atan2f (device and host libm differ in the last bit there;
 those have tolerance tests of their own)."""
 import os
@@ -29,13 +30,15 @@ def _vec(rng, lo, hi):
 
 
 def _texture(rng, depth=0):
-    if depth == 0 and rng.random() < 0.3:
-        return "{type: checker, scale: %.3f, odd: %s, even: %s}" % (rng.uniform(0.2, 1.5), _texture(rng, 1), _texture(rng, 1))
+    if depth < 2 and rng.random() < 0.3:
+        return "{type: checker, scale: %.3f, odd: %s, even: %s}" % (rng.uniform(0.2, 1.5), _texture(rng, depth + 1), _texture(rng, depth + 1))
     return "{type: solid_color, color: %s}" % _vec(rng, 0.05, 0.95)
 
 
-def _material(rng):
+def _material(rng, flat_surface=False):
     kind = rng.random()
+    if flat_surface and kind < 0.15:    # image lookups on triangles are plain arithmetic on the barycentrics
+        return "{type: lambertian, texture: {type: image, filename: %s}}" % rng.choice(["rgb.png", "grey.png", "rgba.png"])
     if kind < 0.45:
         return "{type: lambertian, texture: %s}" % _texture(rng)
     if kind < 0.7:
@@ -67,6 +70,10 @@ def _object(rng, extent, wrappers, depth=0):
         if pick == 3:
             return "{type: sphere, center: [0, -1000, 0], radius: %.3f, material: %s}" % (1000 - extent - rng.uniform(0.0, 1.0), mat)
         return "{type: box, corner1: [1.0e6, 1.0e6, 1.0e6], corner2: [1.0e6, 1.0e6, 1.00001e6], material: %s}" % mat
+    if kind >= 0.45 and kind < 0.93:
+        mat = _material(rng, True)
+        if rng.random() < 0.2:
+            mat += ", normal: {type: image, filename: rgb.png}"
     if kind < 0.45:
         c = _vec(rng, -extent, extent)
         moving = ", center2: %s" % _vec(rng, -extent, extent) if rng.random() < 0.25 else ""
@@ -110,15 +117,27 @@ _COUNTS = (2, 2, 5, 8, 8, 12, 18, 18, 27, 40, 40, 60, 90, 90, 150, 300, 300, 500
 CASES += [(1000 + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.get("CRT_FUZZ_EXTRA", "0")))]
 
 
+@pytest.fixture(scope="module")
+def image_dir(tmp_path_factory):
+    """Small image files the random scenes refer to: 3, 1 and 4 channels, odd sizes."""
+    from PIL import Image
+    d = tmp_path_factory.mktemp("fuzz_images")
+    g = np.random.default_rng(7)
+    Image.fromarray(g.integers(0, 256, (23, 37, 3), dtype=np.uint8), "RGB").save(d / "rgb.png")
+    Image.fromarray(g.integers(0, 256, (16, 16), dtype=np.uint8), "L").save(d / "grey.png")
+    Image.fromarray(g.integers(0, 256, (9, 31, 4), dtype=np.uint8), "RGBA").save(d / "rgba.png")
+    return str(d)
+
+
 @pytest.mark.parametrize("seed,count", CASES)
-def test_random_scene_bit_exact_in_every_mode(crt, oracle, seed, count):
+def test_random_scene_bit_exact_in_every_mode(crt, oracle, image_dir, seed, count):
     from cudaraytracer_amd import api
     text = random_scene(seed, count)
     oracle.oracle_set_pow5_mulchain(1)          # (1-cos)^5 as the device computes it: four multiplications
     try:
         reference = None
         for mode in MODES:
-            sc = crt.parse_scene(text)
+            sc = crt.parse_scene(text, base_dir=image_dir)
             if mode == "ordered":
                 os.environ["CRT_ACCEL"] = "ordered"
             try:
