@@ -154,3 +154,49 @@ def test_zero_bounces_renders_black(crt):
     assert (got["color"] == 0).all() and (got["albedo"] == 0).all() and (got["opacity"] == 0).all()
     buf.close()
     sc.close()
+
+
+@pytest.mark.gpu
+def test_render_from_another_thread(crt):
+    """The preview of the reference calls render() from a thread of its own (preview.cuh:294-315):
+    a scene created on the main thread renders the same bits when called from a second thread,
+    and two scenes render side by side from two threads."""
+    import threading
+    from conftest import scene_path
+    sc = crt.load_scene(scene_path("cornell_box.yaml"), base_dir=scene_path(""))
+    sc.set_render(96, 96, 4, 8)
+    buf = crt.create_buffer(sc)
+    crt.render(sc, buf)
+    want = buf.download()
+    other = crt.load_scene(scene_path("orthographic.yaml"), base_dir=scene_path(""))
+    other.set_render(64, 64, 4, 6)
+    other_buf = crt.create_buffer(other)
+    crt.render(other, other_buf)
+    other_want = other_buf.download()
+
+    results, errors = {}, []
+
+    def worker(name, scene, buffer):
+        try:
+            for s in range(4):                                   # the preview pattern: one sample per call
+                crt.render(scene, buffer, samples=1, samples_done=s)
+            results[name] = buffer.download()
+        except Exception as e:                                   # noqa: BLE001 - reported below
+            errors.append((name, e))
+
+    threads = [threading.Thread(target=worker, args=("cornell", sc, buf)),
+               threading.Thread(target=worker, args=("ortho", other, other_buf))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, ref in ((results["cornell"], want), (results["ortho"], other_want)):
+        for k in got:
+            a, b = got[k], ref[k]
+            # one call of 4 samples and 4 calls of one sample fold the mean differently (last bits)
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True), k
+    for x in (buf, other_buf):
+        x.close()
+    sc.close()
+    other.close()
