@@ -112,7 +112,9 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
 // LDS carve-up of a block: [pass sums: waves x 2 x 14 x 32 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
 constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
-constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave) * 4; }
+constexpr int kCamWords = 32;                    // DevCamera copy of the block
+static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
+constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave) * 4 + kCamWords * 4 / kWaves; }
 
 // One work item of a wave: the 8x4 pixel tile `tile`, samples [s0, s0 + items/32).
 struct WorkItem {
@@ -132,9 +134,14 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     extern __shared__ float4 smem[];
     float* acc_all = reinterpret_cast<float*>(smem);
     uint32_t* coop_all = reinterpret_cast<uint32_t*>(acc_all + kWaves * kAccFloatsPerWave);
-    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave);
+    // The camera is read from LDS where a new path starts: as kernel arguments its 25 values would
+    // sit in scalar registers for the whole kernel, and the compiler, out of scalar registers,
+    // parks them in lanes of a vector register and fetches each one back with a v_readlane.
+    DevCamera* lds_cam = reinterpret_cast<DevCamera*>(coop_all + kWaves * kCoopWordsPerWave);
+    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords);
     float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
     const DevScene& sc = A.sc;
+    if (threadIdx.x == 0) *lds_cam = sc.cam;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][tile pixels] sums of the wave's two open tiles
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
                         pixoff = fill_buffer * kAccFloatsPerTile + pix;
                         rng.init(pj * sc.width + pi, sample);
-                        ray = camera_ray(sc.cam, pi, pj, rng);
+                        ray = camera_ray(*lds_cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
                         pend_albedo = v3(0, 0, 0);
                         bounces = 0;
