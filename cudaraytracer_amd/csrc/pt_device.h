@@ -528,32 +528,47 @@ struct FlatView {                      // part of the kernel arguments
 };
 
 struct FlatLds {
-    const float4* slots;               // [5][slot_count] field-major copy in LDS
+    const float4* slots;               // [slot_count][5] copy in LDS, slots in reverse order (slot of candidate bit b at b)
     const float* xforms;               // transforms of world-group primitives that carry one
     int slot_count;
 };
 
-// One slab test of the box phase; 1 when the box is hit on [tmin, +inf).
+// One slab test of the box phase; the mask of the lanes whose ray hits the box on [tmin, +inf).
 // For a non-empty box min <= max, so the reference's swap on a negative reciprocal
 // (aabb.cuh:144-148) selects exactly fmin/fmax of the two plane distances.
-__device__ __forceinline__ unsigned flat_box_hit(NativeQuad b0, NativeQuad b1, V3 o, V3 inv, float tmin) {
+__device__ __forceinline__ unsigned long long flat_box_hit(NativeQuad b0, NativeQuad b1, V3 o, V3 inv, float tmin) {
     const float ax = (b0.x - o.x) * inv.x, bx = (b0.y - o.x) * inv.x;
     const float ay = (b0.z - o.y) * inv.y, by = (b0.w - o.y) * inv.y;
     const float az = (b1.x - o.z) * inv.z, bz = (b1.y - o.z) * inv.z;
     const float lo = fmaxf(tmin, fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)));
     const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    return (hi < lo) ? 0u : 1u;
+    // !(hi < lo) as a lane mask in scalar registers (written as an instruction: a wave-wide
+    // ballot in the source would keep the slot loop from being unrolled)
+    unsigned long long hit;
+    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(hit) : "v"(hi), "v"(lo));
+    return hit;
+}
+// word = (word << 1) | (this lane's bit of `in`), and the bit shifted out goes to this lane's
+// bit of the result: one add-with-carry, the compare result never leaves the scalar mask.
+__device__ __forceinline__ unsigned long long shift_in(unsigned& word, unsigned long long in) {
+    unsigned long long out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(word), "=s"(out) : "v"(word), "s"(in));
+    return out;
 }
 // Box tests of slots [first, last) -> bits shifted into (hi:lo) from the right, so that slot s
-// ends up at bit (slot_count-1-s): the first slot is the highest set bit.
+// ends up at bit (slot_count-1-s): the first slot is the highest set bit.  WIDE = more than 32
+// slots in the scene (the high word is in use).
+template <bool WIDE>
 __device__ __forceinline__ void flat_box_range(ConstQuadPtr boxes, int first, int last, V3 o, V3 inv, float tmin,
                                                unsigned& lo_word, unsigned& hi_word) {
-#pragma unroll 4
-    for (int s = first; s < last; s++) {
-        const unsigned hit = flat_box_hit(boxes[2 * s], boxes[2 * s + 1], o, inv, tmin);
-        hi_word = (hi_word << 1) | (lo_word >> 31);
-        lo_word = (lo_word << 1) | hit;
-    }
+    auto one = [&](int s) {
+        const unsigned long long hit = flat_box_hit(boxes[2 * s], boxes[2 * s + 1], o, inv, tmin);
+        const unsigned long long carry = shift_in(lo_word, hit);
+        if constexpr (WIDE) (void)shift_in(hi_word, carry);
+    };
+    int s = first;
+    for (; s + 4 <= last; s += 4) { one(s); one(s + 1); one(s + 2); one(s + 3); }    // unrolled by hand: the
+    for (; s < last; s++) one(s);                        // instructions above count as convergent operations
 }
 
 struct TriEval {
@@ -583,7 +598,10 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
     unsigned cand_lo = 0, cand_hi = 0;
-    flat_box_range(boxes, 0, F.group_end[0], r.o, slab_reciprocal(r.d, FAST), tmin, cand_lo, cand_hi);
+    const bool wide = F.slot_count > 32;                      // uniform over the launch
+    const V3 inv0 = slab_reciprocal(r.d, FAST);
+    if (wide) flat_box_range<true>(boxes, 0, F.group_end[0], r.o, inv0, tmin, cand_lo, cand_hi);
+    else flat_box_range<false>(boxes, 0, F.group_end[0], r.o, inv0, tmin, cand_lo, cand_hi);
     // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
     V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
     if constexpr (GROUPS >= 1) {
@@ -591,29 +609,32 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
 #pragma unroll
         for (int k = 0; k < 15; k++) X[k] = gx[k];
         to_object_space(X, r.o, r.d, o1, d1);
-        flat_box_range(boxes, F.group_end[0], F.group_end[1], o1, slab_reciprocal(d1, FAST), tmin, cand_lo, cand_hi);
+        const V3 inv1 = slab_reciprocal(d1, FAST);
+        if (wide) flat_box_range<true>(boxes, F.group_end[0], F.group_end[1], o1, inv1, tmin, cand_lo, cand_hi);
+        else flat_box_range<false>(boxes, F.group_end[0], F.group_end[1], o1, inv1, tmin, cand_lo, cand_hi);
     }
     if constexpr (GROUPS >= 2) {
         float X[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) X[k] = gx[kXformFloats + k];
         to_object_space(X, r.o, r.d, o2, d2);
-        flat_box_range(boxes, F.group_end[1], F.group_end[2], o2, slab_reciprocal(d2, FAST), tmin, cand_lo, cand_hi);
+        const V3 inv2 = slab_reciprocal(d2, FAST);
+        if (wide) flat_box_range<true>(boxes, F.group_end[1], F.group_end[2], o2, inv2, tmin, cand_lo, cand_hi);
+        else flat_box_range<false>(boxes, F.group_end[1], F.group_end[2], o2, inv2, tmin, cand_lo, cand_hi);
     }
 
     Hit best;
     best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
     bool best_tri = false;
-    const int n = L.slot_count;
     CRT_CLOCK(clk, kSecPrim, cand_lo);
     while (cand_lo | cand_hi) {
         CRT_PROF(kProfPrim);
-        int bit;
-        if (cand_hi) { bit = 63 - __builtin_clz(cand_hi); cand_hi &= ~(1u << (bit - 32)); }
-        else { bit = 31 - __builtin_clz(cand_lo); cand_lo &= ~(1u << bit); }
-        const int s = n - 1 - bit;
-        const float4 q0 = L.slots[0 * n + s], q1 = L.slots[1 * n + s], q2 = L.slots[2 * n + s];
-        const float4 q3 = L.slots[3 * n + s], q4 = L.slots[4 * n + s];
+        int bit;                                               // any order will do, see consider()
+        if (cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
+        else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
+        const int s = bit;                                     // the LDS copy is stored last slot first
+        const float4* rec = L.slots + s * kSlotQuads;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
         const int meta = __float_as_int(q4.z), xf = __float_as_int(q4.w);
         const int rank_a = meta & 63, rank_b = (meta >> 6) & 63, group = (meta >> 15) & 3;
         const bool has_b = (meta >> 12) & 1, is_tri = ((meta >> 13) & 3) == 2;

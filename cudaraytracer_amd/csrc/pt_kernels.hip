@@ -89,7 +89,7 @@ __device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const fl
     float* lx = reinterpret_cast<float*>(lds + kSlotQuads * n);
     for (int i = threadIdx.x; i < n * kSlotQuads; i += kBlock) {
         int slot = i / kSlotQuads, q = i - slot * kSlotQuads;
-        lds[q * n + slot] = F.slots[i];
+        lds[(n - 1 - slot) * kSlotQuads + q] = F.slots[i];     // candidate bit b of the box phase = slot n-1-b
     }
     for (int i = threadIdx.x; i < nx * kXformFloats; i += kBlock) lx[i] = xforms[i];
     FlatLds L;
