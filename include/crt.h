@@ -239,7 +239,11 @@ int crt_profile_counters(uint64_t* out64, int reset);
 int crt_scene_set_mode(crt_scene* sc, int mode);
 
 /* Which kernel variant the next render of this scene uses, as text for logs and tests, e.g.
- * "mode=flat slots=18 groups=2 reciprocal=newton stack=8+0 nodes=21 objects=36".
+ * "mode=flat slots=18 groups=2 reciprocal=newton stack=8+0 nodes=21 objects=36 order=free".
+ * order=reference: a primitive of the scene sticks out of the box of its BVH slot (nested
+ * translate/rotate wrappers of the reference do that, hittable.cuh:77-127 against :429), so the
+ * image depends on the order of the reference's walk (bvh.cuh:387-419) and the scene is walked
+ * in exactly that order; order=free: any order gives the same image and the library picks its own.
  * Writes at most `size` bytes including the terminator; returns the full length. */
 int crt_scene_describe(crt_scene* sc, char* text, int size);
 
