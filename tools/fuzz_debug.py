@@ -12,11 +12,18 @@ mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 o = oracle_lib.load()
 o.oracle_set_pow5_mulchain(1)
 text = f.random_scene(seed, count)
-sc = crt.parse_scene(text)
+import tempfile
+from PIL import Image
+image_dir = tempfile.mkdtemp()
+g = np.random.default_rng(7)
+Image.fromarray(g.integers(0, 256, (23, 37, 3), dtype=np.uint8), "RGB").save(os.path.join(image_dir, "rgb.png"))
+Image.fromarray(g.integers(0, 256, (16, 16), dtype=np.uint8), "L").save(os.path.join(image_dir, "grey.png"))
+Image.fromarray(g.integers(0, 256, (9, 31, 4), dtype=np.uint8), "RGBA").save(os.path.join(image_dir, "rgba.png"))
+sc = crt.parse_scene(text, base_dir=image_dir)
 sc.set_mode(mode)
 print(sc.describe(), "env", {k: v for k, v in os.environ.items() if k.startswith("CRT_")})
 dp = crt.lib().crt_host_scene_desc(sc._host)
-w, h = 48, 32
+w, h = sc.desc.render.image_width, sc.desc.render.image_height
 for sample in range(1, 4):
     g = sc.trace_primary(sample)
     r = oracle_lib.trace_primary(o, dp, w, h, sample)
@@ -34,4 +41,5 @@ for done in range(3):
         same = (a == b) | (np.isnan(a) & np.isnan(b))
         if not same.all():
             idx = np.flatnonzero(~same.reshape(w * h, -1).all(axis=1))
-            print("  pass", k, "pixels", idx[:10], "got", a.reshape(w * h, -1)[idx[0]], "want", b.reshape(w * h, -1)[idx[0]])
+            print("  pass", k, "pixels", idx[:10], "got", a.reshape(w * h, -1)[idx[0]], "want", b.reshape(w * h, -1)[idx[0]],
+                  "bits", a.reshape(w * h, -1)[idx[0]].view(np.uint32), b.reshape(w * h, -1)[idx[0]].view(np.uint32))
