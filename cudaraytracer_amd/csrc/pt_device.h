@@ -841,7 +841,17 @@ __device__ __forceinline__ bool sample_accepted(V3 p, bool in_sphere) {
     const float lensq = length_squared(p);
     return in_sphere ? (lensq < 1.0f) : (1e-30f < lensq && lensq <= 1.0f);
 }
-__device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng& rng, volatile uint32_t* pub, volatile float* res, int lane) {
+// Lanes exchange data through LDS inside one wave: LDS executes a wave's instructions in order,
+// so all that is needed between a store and another lane's load is that the compiler keeps
+// them in place (fence + wave barrier).  The pointers are plain, not volatile: a volatile access
+// through a generic pointer is compiled to a flat, system-coherent load or store with a full
+// wait after each, ten of them in a row per round.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng& rng, uint32_t* pub, float* res, int lane) {
     V3 out = v3(0.0f, 0.0f, 0.0f);
     bool pending = false;
     if (need) {
@@ -861,8 +871,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
             pub[2 * rank] = rng.state;
             pub[2 * rank + 1] = rng.draws | (in_sphere ? 0x80000000u : 0u);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         const int target = lane >> log2m, c = lane & (m - 1);
         bool ok = false;
         if (target < pending_count) {
@@ -872,8 +881,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
             res[3 * lane] = p.x; res[3 * lane + 1] = p.y; res[3 * lane + 2] = p.z;
         }
         const unsigned long long okmask = __ballot(ok);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         if (pending) {
             const unsigned sub = (unsigned)(okmask >> (rank << log2m)) & ((1u << m) - 1u);
             if (sub) {
@@ -886,7 +894,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
                 rng.draws += 3u * (uint32_t)m;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();                                    // the next round overwrites pub and res
         mask = __ballot(pending);
     }
     if (need && !in_sphere) out = unit(out);

@@ -145,8 +145,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][tile pixels] sums of the wave's two open tiles
-    volatile uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
-    volatile float* coop_res = reinterpret_cast<volatile float*>(coop_pub + 128);
+    uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
+    float* coop_res = reinterpret_cast<float*>(coop_pub + 128);
 #pragma unroll
     for (int k = 0; k < kAccFloatsPerWave / 64; k++) acc[k * 64 + lane] = 0.0f;
 
