@@ -224,11 +224,17 @@ struct SceneLds {
 // base[e * stride + l] (conflict-free); a walk that goes deeper continues in a per-thread slice
 // of global memory (spill[(e - lds_entries) * spill_stride]), so that LDS use - and with it the
 // number of resident waves - does not grow with the depth of the tree.
+// The two parts are addressed through pointers of their own address space: with generic pointers
+// the compiler folds the two branches of get() into one address select and ONE flat load, and a
+// flat load that ends up in LDS takes the long way round through the vector-memory path - on
+// every pop of the walk.
+typedef int __attribute__((address_space(3))) * LdsIntPtr;
+typedef int __attribute__((address_space(1))) * GlobalIntPtr;
 struct LaneStack {
-    int* base;
+    LdsIntPtr base;
     int stride;
     int lds_entries;
-    int* spill;
+    GlobalIntPtr spill;
     size_t spill_stride;
     __device__ __forceinline__ void put(int e, int v) {
         if (e < lds_entries) base[e * stride] = v;

@@ -159,10 +159,10 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
     __syncthreads();
 
     LaneStack stk;
-    stk.base = stack_mem + threadIdx.x;
+    stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
     stk.stride = kBlock;
     stk.lds_entries = STACK;
-    stk.spill = A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
     stk.spill_stride = (size_t)A.spill_threads;
 
     const int item_count = A.ntiles * A.chunks;
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
             SceneGlobal S;
             S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
             LaneStack stk;
-            stk.base = stack_mem + threadIdx.x;
+            stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
             stk.stride = kBlock;
             stk.lds_entries = STACK;
-            stk.spill = A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+            stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
             stk.spill_stride = (size_t)A.spill_threads;
             h = traverse(S, ray, 0.001f, INFINITY, stk);
         }
