@@ -686,18 +686,18 @@ __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, flo
     int y0 = wrapi((int)yf, img.height), y1 = wrapi((int)yf + 1, img.height);
     out[0] = out[1] = out[2] = out[3] = 0.0f;
     if (img.channels == 4) {
-        const uchar4* p = reinterpret_cast<const uchar4*>(img.pixels);
-        uchar4 a = p[(size_t)y0 * img.width + x0], b = p[(size_t)y0 * img.width + x1];
-        uchar4 c = p[(size_t)y1 * img.width + x0], d = p[(size_t)y1 * img.width + x1];
-        const float ta[4] = {(float)a.x, (float)a.y, (float)a.z, (float)a.w}, tb[4] = {(float)b.x, (float)b.y, (float)b.z, (float)b.w};
-        const float tc[4] = {(float)c.x, (float)c.y, (float)c.z, (float)c.w}, td[4] = {(float)d.x, (float)d.y, (float)d.z, (float)d.w};
+        // (the pointer comes out of memory, so the compiler cannot tell that it points to global memory)
+        const uint32_t __attribute__((address_space(1)))* p = (const uint32_t __attribute__((address_space(1)))*)img.pixels;
+        const uint32_t a = p[(size_t)y0 * img.width + x0], b = p[(size_t)y0 * img.width + x1];     // r | g << 8 | b << 16 | a << 24
+        const uint32_t c = p[(size_t)y1 * img.width + x0], d = p[(size_t)y1 * img.width + x1];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            float t00 = ta[k] * (1.0f / 255.0f), t10 = tb[k] * (1.0f / 255.0f), t01 = tc[k] * (1.0f / 255.0f), t11 = td[k] * (1.0f / 255.0f);
+            float t00 = (float)((a >> (8 * k)) & 255u) * (1.0f / 255.0f), t10 = (float)((b >> (8 * k)) & 255u) * (1.0f / 255.0f);
+            float t01 = (float)((c >> (8 * k)) & 255u) * (1.0f / 255.0f), t11 = (float)((d >> (8 * k)) & 255u) * (1.0f / 255.0f);
             out[k] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
         }
     } else {
-        const uint8_t* p = img.pixels;
+        const uint8_t __attribute__((address_space(1)))* p = (const uint8_t __attribute__((address_space(1)))*)img.pixels;
         float t00 = p[(size_t)y0 * img.width + x0] * (1.0f / 255.0f), t10 = p[(size_t)y0 * img.width + x1] * (1.0f / 255.0f);
         float t01 = p[(size_t)y1 * img.width + x0] * (1.0f / 255.0f), t11 = p[(size_t)y1 * img.width + x1] * (1.0f / 255.0f);
         out[0] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
