@@ -742,6 +742,10 @@ struct Surface {
 
 // Rebuild the record of the closest hit: hit_tri / hit_sphere tail, object->world transform,
 // normal map (hittable.cuh:292-299, 338-356, 367-386, 438-444).
+// ALWAYS_UV = false: the (u, v) of a sphere, an acosf and an atan2f, are only computed for objects
+// on which something reads them (flag bit 1 of the shading record: an image texture under the
+// material or a normal map); the render never looks at them otherwise.
+template <bool ALWAYS_UV>
 __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
     const float4* pq = sc.prims + h.obj * kPrimQuads;
     const float4* sq = sc.shade + h.obj * kShadeQuads;
@@ -760,7 +764,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         float4 s3 = sq[3], s4 = sq[4], s5 = sq[5];
         float w = 1.0f - h.bu - h.bv;
         V3 n;
-        if (__float_as_int(s2.w)) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(s2.x, s2.y, s2.z));
+        if (__float_as_int(s2.w) & 1) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(s2.x, s2.y, s2.z));
         else n = v3(s0.x, s0.y, s0.z);
         s.front = dot(d, n) < 0.0f;
         s.normal = s.front ? n : -n;
@@ -775,10 +779,13 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         V3 outward = (p - center) / radius;
         s.front = dot(d, outward) < 0.0f;
         s.normal = s.front ? outward : -outward;
-        float theta = acosf(-outward.y);                                 // get_sphere_uv
-        float phi = atan2f(-outward.z, outward.x) + kPi;
-        s.u = phi / (2 * kPi);
-        s.v = theta / kPi;
+        s.u = 0.0f; s.v = 0.0f;
+        if (ALWAYS_UV || (__float_as_int(s2.w) & 2)) {
+            float theta = acosf(-outward.y);                             // get_sphere_uv
+            float phi = atan2f(-outward.z, outward.x) + kPi;
+            s.u = phi / (2 * kPi);
+            s.v = theta / kPi;
+        }
         if (normal_idx >= 0) {                                           // get_tangent_bitangent: centre at rec.t
             V3 local_p = p - (c0 + cd * h.t);
             float ph = atan2f(-local_p.z, local_p.x) + kPi;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
-                sf = make_surface(sc, ray, h);
+                sf = make_surface<false>(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
                 mat_type = __float_as_int(m0.x);
             }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
         }
         A.obj[idx] = h.obj;
         if (h.obj >= 0) {
-            Surface sf = make_surface(sc, ray, h);
+            Surface sf = make_surface<true>(sc, ray, h);
             A.t[idx] = h.t; A.u[idx] = sf.u; A.v[idx] = sf.v; A.front[idx] = sf.front ? 1 : 0;
         } else {
             A.t[idx] = INFINITY; A.u[idx] = 0.0f; A.v[idx] = 0.0f; A.front[idx] = 0;
@@ -689,6 +689,22 @@ void reference_visit_order(const crt_bvh4& b, std::vector<int>& leaf_slots) {
     }
 }
 
+// Does anything look at the surface coordinates (u, v) of this object: a normal map, or an image
+// texture somewhere under its material's texture (checkers pass (u, v) on to their children)?
+bool texture_reads_uv(const crt_scene_desc* d, int tex, int depth) {
+    if (tex < 0) return false;
+    if (tex >= d->texture_count || depth > 64) return true;          // out of the ordinary: assume it does
+    const crt_texture& t = d->textures[tex];
+    if (t.type == CRT_TEX_IMAGE) return true;
+    if (t.type == CRT_TEX_CHECKER) return texture_reads_uv(d, t.odd_idx, depth + 1) || texture_reads_uv(d, t.even_idx, depth + 1);
+    return false;
+}
+bool reads_uv(const crt_scene_desc* d, const crt_object& o) {
+    if (o.normal_idx >= 0) return true;
+    if (o.mat_idx < 0 || o.mat_idx >= d->material_count) return true;
+    return texture_reads_uv(d, d->materials[o.mat_idx].tex_idx, 0);
+}
+
 // Does every primitive lie inside the box of its own leaf slot?  The reference shrinks the ray
 // interval to the closest hit so far while it walks (bvh.cuh:398,407-411), so a primitive is
 // only tested if its leaf box is still hit at that moment.  When every box contains its
@@ -863,7 +879,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         float* s = &shade_rec[(size_t)i * kShadeQuads * 4];
         s[0] = o.n0[0]; s[1] = o.n0[1]; s[2] = o.n0[2]; s[3] = as_float(o.mat_idx);
         s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2]; s[7] = as_float(o.normal_idx);
-        s[8] = o.n2[0]; s[9] = o.n2[1]; s[10] = o.n2[2]; s[11] = as_float(o.shade_smooth ? 1 : 0);
+        s[8] = o.n2[0]; s[9] = o.n2[1]; s[10] = o.n2[2]; s[11] = as_float((o.shade_smooth ? 1 : 0) | (reads_uv(d, o) ? 2 : 0));
         s[12] = o.uv0[0]; s[13] = o.uv0[1]; s[14] = o.uv1[0]; s[15] = o.uv1[1];
         s[16] = o.uv2[0]; s[17] = o.uv2[1]; s[18] = o.tangent[0]; s[19] = o.tangent[1];
         s[20] = o.tangent[2]; s[21] = o.bitangent[0]; s[22] = o.bitangent[1]; s[23] = o.bitangent[2];
