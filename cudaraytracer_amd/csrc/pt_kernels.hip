@@ -83,7 +83,7 @@ __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int 
     return m;
 }
 
-// Flat mode: slot records (field-major) and the transforms of world-group primitives.
+// Flat mode: slot records (slot-major, last slot first) and the transforms of world-group primitives.
 __device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const float* xforms, int nx, float4* lds) {
     const int n = F.slot_count;
     float* lx = reinterpret_cast<float*>(lds + kSlotQuads * n);
