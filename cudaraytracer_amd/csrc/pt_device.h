@@ -738,6 +738,8 @@ struct Surface {
     float u, v;
     bool front;
     int mat;
+    bool has_unit;       // unit_normal is unit(normal), taken from the shading record instead of three divisions
+    V3 unit_normal;
 };
 
 // Rebuild the record of the closest hit: hit_tri / hit_sphere tail, object->world transform,
@@ -757,6 +759,8 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     V3 o = r.o, d = r.d;
     if (xf >= 0) to_object_space(X, r.o, r.d, o, d);
     Surface s;
+    s.has_unit = false;
+    s.unit_normal = v3(0.0f, 0.0f, 0.0f);
     s.mat = __float_as_int(s0.w);
     V3 p = o + d * h.t;
     V3 tangent = v3(0, 0, 0), bitangent = v3(0, 0, 0);
@@ -768,6 +772,13 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         else n = v3(s0.x, s0.y, s0.z);
         s.front = dot(d, n) < 0.0f;
         s.normal = s.front ? n : -n;
+        if (__float_as_int(s2.w) & 4) {
+            // flat triangle without a normal map: the host has stored unit(world normal) in the slot of
+            // the second vertex normal; negation commutes with every step of rotating and normalising
+            const V3 pre = v3(s1.x, s1.y, s1.z);
+            s.unit_normal = s.front ? pre : -pre;
+            s.has_unit = true;
+        }
         s.u = w * s3.x + h.bu * s3.z + h.bv * s4.x;
         s.v = w * s3.y + h.bu * s3.w + h.bv * s4.y;
         tangent = v3(s4.z, s4.w, s5.x);

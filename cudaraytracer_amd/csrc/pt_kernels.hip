@@ -309,7 +309,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                 if (scatter_with(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         pend_albedo = attenuation;
-                        V3 n = unit(sf.normal);
+                        V3 n = sf.unit_normal;
+                        if (!sf.has_unit) n = unit(sf.normal);
                         acc_add3<kTilePixels>(acc, 9, pixoff, n);
                         acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
                         acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
                     V3 alb = pend_albedo;
                     if (bounces == 0) {
                         alb = emitted;
-                        V3 n = unit(sf.normal);
+                        V3 n = sf.unit_normal;
+                        if (!sf.has_unit) n = unit(sf.normal);
                         acc_add3<kTilePixels>(acc, 6, pixoff, emitted);
                         acc_add3<kTilePixels>(acc, 9, pixoff, n);
                         acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
@@ -880,6 +882,15 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
         s[0] = o.n0[0]; s[1] = o.n0[1]; s[2] = o.n0[2]; s[3] = as_float(o.mat_idx);
         s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2]; s[7] = as_float(o.normal_idx);
         s[8] = o.n2[0]; s[9] = o.n2[1]; s[10] = o.n2[2]; s[11] = as_float((o.shade_smooth ? 1 : 0) | (reads_uv(d, o) ? 2 : 0));
+        if (o.type == CRT_OBJ_TRI && !o.shade_smooth && o.normal_idx < 0) {
+            // unit(normal) of the normal pass (render.cuh:55), as make_surface() would compute it for a
+            // front-facing hit: the flat normal, rotated if the object is transformed, divided by its length
+            V3 n = v3(o.n0);
+            if (xf >= 0) n = matvec(o.rotation, n);
+            n = unit(n);
+            s[4] = n.x; s[5] = n.y; s[6] = n.z;
+            s[11] = as_float(__builtin_bit_cast(int32_t, s[11]) | 4);
+        }
         s[12] = o.uv0[0]; s[13] = o.uv0[1]; s[14] = o.uv1[0]; s[15] = o.uv1[1];
         s[16] = o.uv2[0]; s[17] = o.uv2[1]; s[18] = o.tangent[0]; s[19] = o.tangent[1];
         s[20] = o.tangent[2]; s[21] = o.bitangent[0]; s[22] = o.bitangent[1]; s[23] = o.bitangent[2];
