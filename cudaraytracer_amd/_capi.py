@@ -68,6 +68,14 @@ class crt_scene_desc(C.Structure):
     ]
 
 
+class crt_scene_options(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("accel", C.c_int32), ("mode", C.c_int32), ("ieee_division", C.c_int32),
+                ("work_items", C.c_int32), ("blocks", C.c_int32), ("ready_percent", C.c_int32), ("prim_batch", C.c_int32),
+                ("deterministic", C.c_int32)]
+
+
+ACCEL_AUTO, ACCEL_REFERENCE, ACCEL_ORDERED = 0, 1, 2
+
 IMAGE_LOADER = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int),
                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8)), C.c_void_p)
 
@@ -87,6 +95,8 @@ SIGNATURES = {
     "crt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "crt_set_device": (C.c_int, [C.c_int]),
     "crt_scene_create": (C.c_int, [C.POINTER(crt_scene_desc), C.POINTER(C.c_void_p)]),
+    "crt_scene_options_init": (C.c_int, [C.POINTER(crt_scene_options)]),
+    "crt_scene_create_ex": (C.c_int, [C.POINTER(crt_scene_desc), C.POINTER(crt_scene_options), C.POINTER(C.c_void_p)]),
     "crt_scene_destroy": (None, [C.c_void_p]),
     "crt_buffers_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "crt_buffers_wrap": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -124,6 +124,7 @@ class Scene:
     def __init__(self, host_handle):
         self._host = C.c_void_p(host_handle)
         self._dev = None
+        self._options = {}
 
     # host side -------------------------------------------------------------------------
     @property
@@ -157,10 +158,24 @@ class Scene:
         return mn, mx, vis
 
     # device side -----------------------------------------------------------------------
+    def set_options(self, **options):
+        """Options of the device copy (fields of crt_scene_options: accel, mode, ieee_division,
+        work_items, blocks, ready_percent, prim_batch, deterministic); drops the device copy."""
+        unknown = set(options) - {name for name, _ in _capi.crt_scene_options._fields_ if name != "struct_size"}
+        if unknown:
+            raise TypeError(f"unknown scene option(s): {sorted(unknown)}")
+        self._drop_device()
+        self._options = dict(options)
+        return self
+
     def upload(self):
         if self._dev is None:
             h = C.c_void_p()
-            _check(_lib.crt_scene_create(_lib.crt_host_scene_desc(self._host), C.byref(h)))
+            opt = _capi.crt_scene_options()
+            _check(_lib.crt_scene_options_init(C.byref(opt)))
+            for name, value in self._options.items():
+                setattr(opt, name, int(value))
+            _check(_lib.crt_scene_create_ex(_lib.crt_host_scene_desc(self._host), C.byref(opt), C.byref(h)))
             self._dev = h
         return self
 

@@ -473,9 +473,11 @@ struct crt_scene {
     FlatView flat = {};
     int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
     bool ordered = false;            // walked in the reference's order (a primitive sticks out of its box)
-    float* partial = nullptr;
+    float* partial = nullptr;        // chunk sums, sized at creation for the largest launch of this scene
     size_t partial_bytes = 0;
-    unsigned long long* ray_counter = nullptr;
+    unsigned long long* ray_counter = nullptr;   // [0] rays traced, [1] next work item
+    unsigned long long* host_counter = nullptr;  // pinned: the ray count of the last launch lands here
+    crt_scene_options opt = {};
     bool launched = false;
 };
 
@@ -591,6 +593,7 @@ void free_scene(crt_scene* sc) {
     if (sc->blob) (void)hipFree(sc->blob);
     if (sc->partial) (void)hipFree(sc->partial);
     if (sc->ray_counter) (void)hipFree(sc->ray_counter);
+    if (sc->host_counter) (void)hipHostFree(sc->host_counter);
     if (sc->stack_spill) (void)hipFree(sc->stack_spill);
     if (sc->ev_start) (void)hipEventDestroy(sc->ev_start);
     if (sc->ev_mid) (void)hipEventDestroy(sc->ev_mid);
@@ -750,6 +753,33 @@ bool primitives_inside_their_boxes(const crt_scene_desc* d) {
     return true;
 }
 
+// How a launch of `samples` samples is cut into work items: every pixel tile x a chunk of the
+// samples.  About 16 items per resident wave keep the end of the launch (waves running dry one by
+// one) to a few percent of its length.  `capacity` = bytes of chunk-sum scratch available.
+struct ChunkPlan {
+    int tile_h, tiles_x, tiles_y, ntiles, pix_padded, chunk_size, chunks;
+    size_t bytes;          // chunk sums of this plan
+    bool fits;
+};
+ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacity) {
+    ChunkPlan p;
+    p.tile_h = tile_rows(mode);
+    p.tiles_x = (sc->dev.width + kTileW - 1) / kTileW;
+    p.tiles_y = (sc->dev.height + p.tile_h - 1) / p.tile_h;
+    p.ntiles = p.tiles_x * p.tiles_y;
+    p.pix_padded = p.ntiles * kTileW * p.tile_h;
+    const size_t chunk_bytes = (size_t)kPasses * p.pix_padded * sizeof(float);
+    const int target_items = sc->opt.work_items > 0 ? sc->opt.work_items : 65536;
+    long long chunks = sc->opt.deterministic ? samples : std::min<long long>(samples, std::max(1, (target_items + p.ntiles - 1) / p.ntiles));
+    p.fits = chunk_bytes <= capacity;
+    if (!sc->opt.deterministic) chunks = std::max<long long>(1, std::min<long long>(chunks, (long long)(capacity / chunk_bytes)));
+    else if ((size_t)chunks * chunk_bytes > capacity) p.fits = false;
+    p.chunk_size = (int)((samples + chunks - 1) / chunks);
+    p.chunks = (samples + p.chunk_size - 1) / p.chunk_size;
+    p.bytes = (size_t)p.chunks * chunk_bytes;
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -770,20 +800,41 @@ int crt_set_device(int device) {
     return CRT_OK;
 }
 
-int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
+int crt_scene_options_init(crt_scene_options* options) {
+    crt::clear_error();
+    if (!options) return crt::set_error(CRT_ERR_INVALID, "crt_scene_options_init: null argument");
+    std::memset(options, 0, sizeof(*options));
+    options->struct_size = (int32_t)sizeof(*options);
+    return CRT_OK;
+}
+
+int crt_scene_create(const crt_scene_desc* d, crt_scene** out) { return crt_scene_create_ex(d, nullptr, out); }
+
+int crt_scene_create_ex(const crt_scene_desc* d, const crt_scene_options* options, crt_scene** out) {
     crt::clear_error();
     if (!d || !out) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: null argument");
+    crt_scene_options opt;
+    std::memset(&opt, 0, sizeof(opt));
+    if (options) {
+        if (options->struct_size <= 0 || options->struct_size > (int32_t)sizeof(opt))
+            return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->struct_size is not set (use crt_scene_options_init)");
+        std::memcpy(&opt, options, (size_t)options->struct_size);
+    }
+    opt.struct_size = (int32_t)sizeof(opt);
+    if (opt.accel < CRT_ACCEL_AUTO || opt.accel > CRT_ACCEL_ORDERED) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->accel must be CRT_ACCEL_*");
+    if (opt.mode < 0 || opt.mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->mode must be 0..3");
+    if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
+        return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
     int bvh_depth = 0;
     std::string why;
     if (validate(d, bvh_depth, why) != CRT_OK) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: " + why);
     // The hierarchy the tree modes walk: built here over the reference tree's leaf slots (see
-    // accel_build.cpp); CRT_ACCEL=reference walks the reference tree itself.
+    // accel_build.cpp); CRT_ACCEL_REFERENCE walks the reference tree itself.
     std::vector<AccelNode> accel;
     int accel_depth = bvh_depth;
-    // CRT_ACCEL=ordered: the reference's tree in the reference's order, whatever the scene.
-    const std::string accel_env = std::getenv("CRT_ACCEL") ? std::getenv("CRT_ACCEL") : "";
-    const bool ordered = accel_env == "ordered" || !primitives_inside_their_boxes(d);
-    if (ordered || accel_env == "reference") accel_from_reference(d->bvh, accel);
+    // CRT_ACCEL_ORDERED: the reference's tree in the reference's order, whatever the scene.
+    const bool ordered = opt.accel == CRT_ACCEL_ORDERED || !primitives_inside_their_boxes(d);
+    if (ordered || opt.accel == CRT_ACCEL_REFERENCE) accel_from_reference(d->bvh, accel);
     else build_accel(d->bvh, accel, accel_depth);
     // A node pushes at most 4 children and pops one before descending: <= 3*(depth-1)+1 live entries.
     int need = 3 * (accel_depth - 1) + 1;
@@ -1068,7 +1119,7 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     D.max_bounces = d->render.max_bounces;
     D.root_entry = accel_leafy(0) ? 1 : 0;
     D.fast_rcp = fast_reciprocal_is_exact(d) ? 1 : 0;
-    if (const char* e = std::getenv("CRT_FAST_RCP")) D.fast_rcp = std::atoi(e) ? D.fast_rcp : 0;   // 0 forces IEEE division
+    if (opt.ieee_division) D.fast_rcp = 0;
     const crt_camera& c = d->camera;
     D.cam.type = c.type;
     D.cam.defocus_angle = c.defocus_angle;
@@ -1095,7 +1146,21 @@ int crt_scene_create(const crt_scene_desc* d, crt_scene** out) {
     for (int g = 0; g <= kMaxFlatGroups; g++) sc->flat.group_end[g] = flat_group_end[g];
     sc->flat.groups = flat_groups;
     sc->lds_flat_bytes = (int)((size_t)sc->flat.slot_count * kSlotQuads * 16 + xforms.size() * 4);
-    if (const char* e = std::getenv("CRT_MODE")) sc->mode = std::atoi(e);
+    sc->mode = opt.mode;
+    sc->opt = opt;
+    // Chunk sums: sized here for the largest launch this scene can ask for, so that a render
+    // allocates nothing.  A launch cuts the frame into about `work_items` items (tile x chunk of
+    // the samples), so the number of chunks is bounded by work_items / tiles whatever the sample
+    // count; the 8x4-pixel tiling of the tree modes has the larger padded pixel count.
+    {
+        const ChunkPlan worst = plan_chunks(sc, kModeTreeGlobal, std::max(1, d->render.samples_per_pixel), (size_t)-1);
+        const ChunkPlan worst_flat = plan_chunks(sc, kModeFlat, std::max(1, d->render.samples_per_pixel), (size_t)-1);
+        sc->partial_bytes = std::max(worst.bytes, worst_flat.bytes);
+        hipError_t e = hipMalloc((void**)&sc->partial, sc->partial_bytes);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&sc->host_counter, sizeof(unsigned long long), hipHostMallocDefault);
+        if (e != hipSuccess) { free_scene(sc); return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: scratch allocation: ") + hipGetErrorString(e)); }
+        *sc->host_counter = 0;
+    }
     *out = sc;
     return CRT_OK;
 }
@@ -1182,72 +1247,74 @@ int crt_buffers_upload(crt_buffers* b, const float* color, const float* albedo, 
     return CRT_OK;
 }
 
-int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done) {
-    crt::clear_error();
-    if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: null argument");
-    if (buf->width != sc->dev.width || buf->height != sc->dev.height) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: buffer size does not match the scene");
-    if (samples <= 0 || first_sample < 0) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: samples must be positive");
-    if (sc->launched) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: a render is already in flight on this scene");
+// Where a launch keeps its chunk sums and counters.
+struct ScratchView {
+    unsigned long long* counters;    // [0] rays traced, [1] next work item
+    float* partial;
+    size_t partial_bytes;
+};
+
+static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done, const ScratchView& S, const char* who) {
+    if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": null argument");
+    if (buf->width != sc->dev.width || buf->height != sc->dev.height) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": buffer size does not match the scene");
+    if (samples <= 0 || first_sample < 0) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": samples must be positive");
+    if (sc->launched) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": a render is already in flight on this scene");
     CRT_HIP(hipSetDevice(sc->device));
+    const ChunkPlan plan = plan_chunks(sc, kernel_mode(sc), samples, S.partial_bytes);
+    if (!plan.fits)
+        return crt::set_error(CRT_ERR_UNSUPPORTED, std::string(who) + ": the chunk sums of this launch (" + std::to_string(sc->opt.deterministic ? (size_t)samples * kPasses * plan.pix_padded * sizeof(float) : (size_t)kPasses * plan.pix_padded * sizeof(float)) +
+                                                       " bytes) exceed the scratch available (" + std::to_string(S.partial_bytes) + " bytes)");
     RenderArgs A;
     A.sc = sc->dev;
-    const int tile_h = tile_rows(kernel_mode(sc));
-    A.tiles_x = (sc->dev.width + kTileW - 1) / kTileW;
-    A.tiles_y = (sc->dev.height + tile_h - 1) / tile_h;
-    A.ntiles = A.tiles_x * A.tiles_y;
-    A.pix_padded = A.ntiles * kTileW * tile_h;
-    // Work items: every 8x4 tile x a chunk of the samples.  About 16 items per resident wave keep
-    // the end of the launch (waves running dry one by one) to a few percent of its length.
-    int target_waves = 65536;
-    if (const char* e = std::getenv("CRT_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
-    int chunks = std::min(samples, std::max(1, (target_waves + A.ntiles - 1) / A.ntiles));
-    A.chunk_size = (samples + chunks - 1) / chunks;
-    chunks = (samples + A.chunk_size - 1) / A.chunk_size;
+    A.tiles_x = plan.tiles_x;
+    A.tiles_y = plan.tiles_y;
+    A.ntiles = plan.ntiles;
+    A.pix_padded = plan.pix_padded;
+    A.chunk_size = plan.chunk_size;
+    A.chunks = plan.chunks;
     A.first_sample = first_sample;
     A.samples = samples;
     A.flat = sc->flat;
-    size_t need = (size_t)chunks * kPasses * A.pix_padded * sizeof(float);
-    if (need > sc->partial_bytes) {
-        if (sc->partial) CRT_HIP(hipFree(sc->partial));
-        sc->partial = nullptr;
-        sc->partial_bytes = 0;
-        CRT_HIP(hipMalloc((void**)&sc->partial, need));
-        sc->partial_bytes = need;
-    }
-    A.partial = sc->partial;
-    A.chunks = chunks;
+    A.partial = S.partial;
     A.stack_spill = sc->stack_spill;
     A.spill_threads = sc->spill_threads;
-    A.prim_batch = 8;
-    if (const char* e = std::getenv("CRT_PRIM_BATCH")) A.prim_batch = std::min(64, std::max(1, std::atoi(e)));
-    A.ready_percent = 65;
-    if (const char* e = std::getenv("CRT_READY_PERCENT")) A.ready_percent = std::min(100, std::max(1, std::atoi(e)));
-    A.ray_counter = sc->ray_counter;
-    A.queue = reinterpret_cast<unsigned int*>(sc->ray_counter + 1);
-    CRT_HIP(hipMemsetAsync(sc->ray_counter, 0, 2 * sizeof(unsigned long long), sc->stream));
+    A.prim_batch = sc->opt.prim_batch > 0 ? sc->opt.prim_batch : 8;
+    A.ready_percent = sc->opt.ready_percent > 0 ? sc->opt.ready_percent : 65;
+    A.ray_counter = S.counters;
+    A.queue = reinterpret_cast<unsigned int*>(S.counters + 1);
+    CRT_HIP(hipMemsetAsync(S.counters, 0, 2 * sizeof(unsigned long long), sc->stream));
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
-    const long long items = (long long)A.ntiles * chunks;
+    const long long items = (long long)plan.ntiles * plan.chunks;
     int resident = sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves);   // 4 SIMDs per CU
-    if (const char* e = std::getenv("CRT_BLOCKS")) resident = std::min(sc->spill_threads / kBlock, std::max(1, std::atoi(e)));
+    if (sc->opt.blocks > 0) resident = std::min(sc->spill_threads / kBlock, sc->opt.blocks);
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
     int rc = launch_fused(sc, A, grid);
     if (rc != CRT_OK) return rc;
     CRT_HIP(hipEventRecord(sc->ev_mid, sc->stream));
     ResolveArgs R;
-    R.partial = sc->partial;
+    R.partial = S.partial;
     R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
     R.depth = buf->depth(); R.opacity = buf->opacity();
-    R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = A.tiles_x; R.tile_rows = tile_h; R.ntiles = A.ntiles; R.pix_padded = A.pix_padded;
-    R.chunks = chunks;
+    R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = plan.tiles_x; R.tile_rows = plan.tile_h; R.ntiles = plan.ntiles; R.pix_padded = plan.pix_padded;
+    R.chunks = plan.chunks;
     R.done = (float)fold_done;
     R.count = (float)samples;
     R.fold = fold_done > 0 ? 1 : 0;
-    hipLaunchKernelGGL(resolve_passes, dim3((A.pix_padded + kBlock - 1) / kBlock), dim3(kBlock), 0, sc->stream, R);
+    hipLaunchKernelGGL(resolve_passes, dim3((plan.pix_padded + kBlock - 1) / kBlock), dim3(kBlock), 0, sc->stream, R);
     CRT_HIP(hipGetLastError());
     CRT_HIP(hipEventRecord(sc->ev_stop, sc->stream));
+    // the ray count travels to pinned host memory behind the kernels; crt_render_finish only waits
+    CRT_HIP(hipMemcpyAsync(sc->host_counter, S.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, sc->stream));
     sc->launched = true;
     return CRT_OK;
+}
+
+int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: null argument");
+    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes};
+    return launch_render(sc, buf, first_sample, samples, fold_done, S, "crt_render_launch");
 }
 
 int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {
@@ -1263,11 +1330,7 @@ int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {
     }
     CRT_HIP(hipEventElapsedTime(&sc->last_trace_ms, sc->ev_start, sc->ev_mid));
     CRT_HIP(hipEventElapsedTime(&sc->last_resolve_ms, sc->ev_mid, sc->ev_stop));
-    if (rays_out) {
-        unsigned long long r = 0;
-        CRT_HIP(hipMemcpy(&r, sc->ray_counter, sizeof(r), hipMemcpyDeviceToHost));
-        *rays_out = r;
-    }
+    if (rays_out) *rays_out = *sc->host_counter;
     return CRT_OK;
 }
 

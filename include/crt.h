@@ -176,9 +176,35 @@ int crt_device_count(int* count);
 /* Select the GPU the calling process renders on (one process per GPU). */
 int crt_set_device(int device);
 
+/* How a scene is prepared and rendered.  Every field has a default (0) that
+ * crt_scene_options_init() sets; crt_scene_create() uses the defaults.  Nothing in the
+ * library reads the process environment. */
+enum { CRT_ACCEL_AUTO = 0,        /* own hierarchy over the reference's leaf boxes; the reference's
+                                     tree in the reference's order when the image depends on it   */
+       CRT_ACCEL_REFERENCE = 1,   /* walk the reference's BVH4 (bvh.cuh:299-310), nearest child first */
+       CRT_ACCEL_ORDERED = 2 };   /* the reference's BVH4 in the order of bvh.cuh:387-419          */
+typedef struct crt_scene_options {
+    int32_t struct_size;      /* sizeof(crt_scene_options), set by crt_scene_options_init      */
+    int32_t accel;            /* CRT_ACCEL_*                                                   */
+    int32_t mode;             /* initial geometry access mode, see crt_scene_set_mode          */
+    int32_t ieee_division;    /* 1: never use the Newton-refined reciprocal                    */
+    int32_t work_items;       /* work items (pixel tile x sample chunk) a frame is cut into; 0 = 65536 */
+    int32_t blocks;           /* workgroups of the persistent render kernel; 0 = fill the GPU  */
+    int32_t ready_percent;    /* tree walk: shade once this share of a wave's rays is done; 0 = 65 */
+    int32_t prim_batch;       /* tree walk: lanes with leaf candidates that start a test round; 0 = 8 */
+    int32_t deterministic;    /* 1: one sample per chunk, so every pixel sum is added in sample order and
+                                 a render is bit-reproducible from run to run (costs 56 B of scratch per
+                                 pixel AND sample instead of per pixel and chunk; a call may then render
+                                 at most samples_per_pixel samples)                              */
+} crt_scene_options;
+int crt_scene_options_init(crt_scene_options* options);
+
 /* scene::scene() upload (scene.cuh:61-89): validates the description, repacks it into
- * the device layout and copies it to HBM. */
+ * the device layout and copies it to HBM.  All device memory a render of this scene needs
+ * (chunk sums, counters, traversal stacks) is allocated here; crt_render allocates nothing,
+ * like render() (render.cuh:167-181). */
 int crt_scene_create(const crt_scene_desc* desc, crt_scene** out);
+int crt_scene_create_ex(const crt_scene_desc* desc, const crt_scene_options* options, crt_scene** out);
 void crt_scene_destroy(crt_scene* sc);
 
 /* create_buffer() (buffer.cuh:344-380).  The six arrays are laid out like the reference:

@@ -140,11 +140,8 @@ def test_random_scene_bit_exact_in_every_mode(crt, oracle, image_dir, seed, coun
         for mode in MODES:
             sc = crt.parse_scene(text, base_dir=image_dir)
             if mode == "ordered":
-                os.environ["CRT_ACCEL"] = "ordered"
-            try:
-                sc.set_mode(MODES[mode])        # uploads the scene
-            finally:
-                os.environ.pop("CRT_ACCEL", None)
+                sc.set_options(accel=2)         # CRT_ACCEL_ORDERED
+            sc.set_mode(MODES[mode])            # uploads the scene
             assert mode != "ordered" or "order=reference" in sc.describe()
             assert seed % 2 or mode == "ordered" or "order=free" in sc.describe()
             dp = crt.lib().crt_host_scene_desc(sc._host)

@@ -247,20 +247,18 @@ def test_fast_reciprocal_variant_is_bit_identical(crt):
     assert "raw v_rcp_f32 (control): 0 mismatches" not in out          # the check can fail
 
     images = []
-    for flag in ("1", "0"):
-        os.environ["CRT_FAST_RCP"] = flag
-        try:
-            for name, mode in (("cornell_box.yaml", 0), ("features_tree.yaml", 1)):
-                sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
-                sc.set_render(128, 96, samples=6)
-                sc.set_mode(mode)
-                buf = crt.create_buffer(sc)
-                crt.render(sc, buf)
-                images.append(buf.download())
-                buf.close()
-                sc.close()
-        finally:
-            del os.environ["CRT_FAST_RCP"]
+    for ieee_division in (0, 1):
+        for name, mode in (("cornell_box.yaml", 0), ("features_tree.yaml", 1)):
+            sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
+            sc.set_render(128, 96, samples=6)
+            sc.set_options(ieee_division=ieee_division)
+            sc.set_mode(mode)
+            assert ("reciprocal=ieee" in sc.describe()) == bool(ieee_division)
+            buf = crt.create_buffer(sc)
+            crt.render(sc, buf)
+            images.append(buf.download())
+            buf.close()
+            sc.close()
     for fast, ieee in ((images[0], images[2]), (images[1], images[3])):
         for k in oracle_lib.PASSES:
             assert np.array_equal(fast[k].view(np.uint32), ieee[k].view(np.uint32)), k

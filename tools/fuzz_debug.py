@@ -20,8 +20,11 @@ Image.fromarray(g.integers(0, 256, (23, 37, 3), dtype=np.uint8), "RGB").save(os.
 Image.fromarray(g.integers(0, 256, (16, 16), dtype=np.uint8), "L").save(os.path.join(image_dir, "grey.png"))
 Image.fromarray(g.integers(0, 256, (9, 31, 4), dtype=np.uint8), "RGBA").save(os.path.join(image_dir, "rgba.png"))
 sc = crt.parse_scene(text, base_dir=image_dir)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dev_options
+sc.set_options(**dev_options.from_env())
 sc.set_mode(mode)
-print(sc.describe(), "env", {k: v for k, v in os.environ.items() if k.startswith("CRT_")})
+print(sc.describe(), "options", dev_options.from_env())
 dp = crt.lib().crt_host_scene_desc(sc._host)
 w, h = sc.desc.render.image_width, sc.desc.render.image_height
 for sample in range(1, 4):

@@ -14,6 +14,9 @@ t_load = time.time()
 sc = crt.load_scene(os.path.join(os.path.dirname(__file__), "..", "scenes", name), base_dir=os.path.join(os.path.dirname(__file__), "..", "scenes"))
 if len(sys.argv) > 3:
     sc.set_render(samples=int(sys.argv[3]))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dev_options
+sc.set_options(**dev_options.from_env())
 print(f"{name}: scene load + BVH build {time.time() - t_load:.2f} s, {sc.desc.object_count} objects", flush=True)
 t_up = time.time()
 sc.upload()
