@@ -4,8 +4,8 @@ The compute lives in libcrt_hip.so (hand-written HIP for gfx950, see csrc/); thi
 the thin host-side mirror of the reference's interface on top of the library's C ABI.
 """
 from .api import (Buffer, CrtError, PASS_NAMES, Scene, bvh4_build, create_buffer, device_count, lib, load_image, load_scene,
-                  parse_scene, pillow_image_loader, render, render_finish, render_launch, render_range, set_device, set_image_loader, version)
+                  parse_scene, pillow_image_loader, render, render_finish, render_launch, render_range, render_static, set_device, set_image_loader, version)
 
 __all__ = ["Buffer", "CrtError", "PASS_NAMES", "Scene", "bvh4_build", "create_buffer", "device_count", "lib", "load_image",
-           "load_scene", "parse_scene", "pillow_image_loader", "render", "render_finish", "render_launch", "render_range", "set_device",
+           "load_scene", "parse_scene", "pillow_image_loader", "render", "render_finish", "render_launch", "render_range", "render_static", "set_device",
            "set_image_loader", "version"]

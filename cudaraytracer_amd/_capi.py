@@ -104,6 +104,7 @@ SIGNATURES = {
     "crt_buffers_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "crt_buffers_upload": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "crt_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "crt_render_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_render_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_scene_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "crt_render_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),

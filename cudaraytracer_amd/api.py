@@ -327,6 +327,18 @@ def render(scene, buf, tx=8, ty=8, samples=-1, samples_done=0):
     return secs.value
 
 
+def render_static(scene, buf, samples=-1, samples_done=0):
+    """render() through crt_render_static: no device allocation in the call (scratch is a fixed
+    64 MiB array inside the library); raises CrtError for images beyond about 1.19 M pixels."""
+    global last_ray_count
+    secs = C.c_float(0)
+    rays = C.c_uint64(0)
+    _check(_lib.crt_render_static(scene.get_device_scene(), buf.get_device_buffer(), samples, samples_done, C.byref(secs),
+                                  C.byref(rays)))
+    last_ray_count = rays.value
+    return secs.value
+
+
 def render_range(scene, buf, first_sample, samples):
     """Mean of sample numbers first_sample+1 .. first_sample+samples (multi-GPU sharding)."""
     secs = C.c_float(0)

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -454,6 +455,32 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
 // ====================================================================== host side =======
 using namespace crt;
 
+// Scratch of crt_render_static(), the entry point for callers that must not allocate: counters
+// (first 256 bytes) and chunk sums.  One copy per GPU, held until the process ends.  In host code
+// the array's name is only a handle for hipGetSymbolAddress(); the device address it yields (one
+// per device, taken with that device current) is what every launch and memset uses.
+constexpr size_t kStaticCounterBytes = 256;
+constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static unsigned char* g_static_scratch[kMaxDevices];     // device address of `scratch` on each GPU
+static std::mutex g_static_scratch_mutex;
+
+// Device address of `scratch` on `device`, which must be the calling thread's current device.
+static hipError_t static_scratch_address(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (!g_static_scratch[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_scratch[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_static_scratch[device];
+    return hipSuccess;
+}
+
 struct crt_scene {
     int device = 0, cu_count = 256;
     hipStream_t stream = nullptr;
@@ -477,6 +504,7 @@ struct crt_scene {
     size_t partial_bytes = 0;
     unsigned long long* ray_counter = nullptr;   // [0] rays traced, [1] next work item
     unsigned long long* host_counter = nullptr;  // pinned: the ray count of the last launch lands here
+    unsigned char* static_scratch = nullptr;     // this GPU's copy of `scratch` (crt_render_static)
     crt_scene_options opt = {};
     bool launched = false;
 };
@@ -1065,6 +1093,7 @@ int crt_scene_create_ex(const crt_scene_desc* d, const crt_scene_options* option
         if (e_ != hipSuccess) { free_scene(sc); return crt::set_error(CRT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } \
     } while (0)
     CRT_HIP_OR_FREE(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    CRT_HIP_OR_FREE(static_scratch_address(sc->device, &sc->static_scratch));
     CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_start));
     CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_mid));
     CRT_HIP_OR_FREE(hipEventCreate(&sc->ev_stop));
@@ -1383,6 +1412,33 @@ int crt_render(crt_scene* sc, crt_buffers* buf, int samples, int samples_done, f
         return CRT_OK;
     }
     int rc = crt_render_launch(sc, buf, samples_done, samples, samples_done);
+    if (rc != CRT_OK) return rc;
+    float ms = 0.0f;
+    rc = crt_render_finish(sc, &ms, rays_out);
+    if (seconds_out) *seconds_out = ms * 1e-3f;
+    return rc;
+}
+
+int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_done, float* seconds_out, uint64_t* rays_out) {
+    crt::clear_error();
+    if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, "crt_render_static: null argument");
+    if (samples_done < 0) return crt::set_error(CRT_ERR_INVALID, "crt_render_static: samples_done must be >= 0");
+    if (samples < 0) samples = sc->render.samples_per_pixel;                       // render.cuh:120-124
+    else samples = std::min(samples, sc->render.samples_per_pixel);
+    if (samples == 0) {
+        if (seconds_out) *seconds_out = 0.0f;
+        if (rays_out) *rays_out = 0;
+        return CRT_OK;
+    }
+    if (!sc->static_scratch) {                              // (set at scene creation; kept for safety)
+        CRT_HIP(hipSetDevice(sc->device));
+        CRT_HIP(static_scratch_address(sc->device, &sc->static_scratch));
+    }
+    // launch_render() cuts the frame into as many sample chunks as fit the array and refuses an
+    // image whose sums of a single chunk (56 bytes per padded pixel) do not
+    const ScratchView S = {reinterpret_cast<unsigned long long*>(sc->static_scratch),
+                           reinterpret_cast<float*>(sc->static_scratch + kStaticCounterBytes), kStaticScratchBytes - kStaticCounterBytes};
+    int rc = launch_render(sc, buf, samples_done, samples, samples_done, S, "crt_render_static");
     if (rc != CRT_OK) return rc;
     float ms = 0.0f;
     rc = crt_render_finish(sc, &ms, rays_out);

@@ -236,6 +236,22 @@ int crt_buffers_upload(crt_buffers* buf, const float* color, const float* albedo
 int crt_render(crt_scene* sc, crt_buffers* buf, int samples, int samples_done,
                float* seconds_out, uint64_t* rays_out);
 
+/* crt_render() for callers that cannot allocate device memory at all (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, semantics and kernels as crt_render(), but the chunk sums and
+ * counters live in a 64 MiB array that is part of the library's code object (one copy per GPU,
+ * held until the process ends) instead of the scratch the scene owns, and the call itself runs no
+ * hipMalloc/hipFree.  Limits: one chunk of sums = 56 bytes per pixel of the image padded to 8x8
+ * (8x4 in the tree modes) tiles must fit, i.e. at most about 1.19 M pixels (1000x1000 fits,
+ * 1280x1024 does not) - larger images get CRT_ERR_UNSUPPORTED; with fewer chunks than crt_render()
+ * would use, the launch has fewer work items and balances worse (1000x1000: 1 chunk instead of 5).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two scenes, two
+ * threads) race.  Sums are added in a different grouping than in crt_render() when the chunk
+ * counts differ, so results agree to float summation order, and bit for bit when both calls use one
+ * sample per chunk (small images, or crt_scene_options.deterministic). */
+int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_done,
+                      float* seconds_out, uint64_t* rays_out);
+
 /* Multi-GPU form: render sample numbers first_sample+1 .. first_sample+samples and leave
  * their MEAN in `buf` (overwriting it), without the samples_per_pixel clamp.  Ranks then
  * combine means weighted by their sample counts. */
