@@ -2,15 +2,18 @@
 """Headline benchmark: Mrays/s of the path-tracing hot path on the Cornell box
 (1000x1000, 50 spp, 15 bounces) on N MI355X of one node.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--scene S] [--scaling strong|weak] [--sharding auto|samples|tiles]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one full render of the scene per GPU.  With N GPUs rank k renders sample numbers
-k*spp+1 .. (k+1)*spp of every pixel (weak scaling: per-GPU work is fixed, the image gets N*spp
-samples) and the ranks' means are combined by one RCCL all-reduce of the 14*W*H pass floats,
-which runs while the next frame renders (every all-reduce completes inside the timed region).
-Inputs (scene in HBM, pass buffers allocated) are resident before the timed region; the timed
-region contains the render kernels, the resolve kernel and the all-reduce.
+A step = one full render of the scene's frame.  With N GPUs the default is STRONG scaling: the
+same frame (the scene's own sample count) is divided over the ranks, either by image tiles (row
+bands dealt round-robin, every rank renders all samples of its rows, one all-gather + a copy
+kernel) or by sample ranges (every rank renders part of the samples of every pixel, one all-reduce
+of the 14*W*H pass floats); `--sharding auto` picks by predicted cost (multi_gpu.choose_sharding).
+`--scaling weak` gives every rank the scene's full sample count (the image gets N times the
+samples).  The collective of frame k runs while frame k+1 renders; every collective completes
+inside the timed region.  Inputs (scene in HBM, pass buffers allocated) are resident before the
+timed region; the timed region contains the render kernels, the resolve kernel and the collective.
 
 A ray = one closest-hit query = one call of bvh4_hit at the reference's render.cuh:47; the
 kernels count them on the device.
@@ -21,23 +24,44 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Algorithmic work per ray under the reference traversal order (survey constants):
-#   flops/ray F = 24*N_box + 84*N_prim + 60*N_accept + 100, bytes/ray B = 128 (path state + hit record)
-FLOPS_PER_RAY = {"cornell_box.yaml": 1116.0, "orthographic.yaml": 485.0, "obj.yaml": 1488.0}
-BYTES_PER_RAY = 128.0
-PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 peak
+# Reference-algorithm work per ray: what the REFERENCE's traversal (bvh.cuh:380-421, unordered
+# stack walk) executes per closest-hit query, counted with the CPU oracle at reduced image size:
+#   flops/ray F = 24*N_box + 84*N_prim + 60*N_accept + 100
+#   (box test 21 flop + 3 reciprocals, primitive test 39 + 45, accepted hit 60, scatter/RNG/accumulate 100)
+# It is the yardstick for "useful work", not a count of the instructions these kernels issue
+# (they test fewer boxes: own hierarchy, nearest child first).
+#   scene: (N_pop, N_box, N_prim, N_accept) per ray
+REFERENCE_COUNTS = {
+    "orthographic.yaml": (2.809, 11.236, 1.018, 0.497),
+    "cornell_box.yaml": (7.743, 30.973, 2.527, 0.997),
+    "obj.yaml": (12.393, 49.572, 2.100, 0.663),
+    "materials.yaml": (4.193, 16.773, 2.209, 0.974),
+    "materials_hdr.yaml": (4.193, 16.773, 2.209, 0.974),
+    "mesh1m.yaml": (36.837, 147.349, 2.955, 0.832),
+    "hdr_env.yaml": (1.000, 4.000, 0.810, 0.296),
+    "normal_map_without.yaml": (1.000, 4.000, 1.048, 0.524),
+}
+STATE_BYTES_PER_RAY = 128.0  # path state + hit record a multi-kernel wavefront design would move per ray
+PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 peak (packed FMA)
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak
+HEADLINE = "cornell_box.yaml"
+
+
+def flops_per_ray(scene):
+    c = REFERENCE_COUNTS.get(scene)
+    return None if c is None else 24.0 * c[1] + 84.0 * c[2] + 60.0 * c[3] + 100.0
 
 
 def measured_traffic(scene):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate
-    rocprofv3 --pmc runs, corrected as the gfx950 notes prescribe); None if not measured."""
+    rocprofv3 --pmc runs of FETCH_SIZE and WRITE_SIZE); None if this scene was not measured."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             return json.load(f)[scene]["bytes_per_launch"]
@@ -45,23 +69,58 @@ def measured_traffic(scene):
         return None
 
 
-def cpu_baseline(scene_file, width, height, spp, threads):
-    """Oracle (CPU restatement of the reference) timed on the host cores on a bounded sample of
-    the same workload: the full-size image at a reduced sample count."""
+def ensure_assets(scene):
+    """mesh1m.yaml reads a generated 1 002 528-triangle height field that is not kept in git."""
+    if scene == "mesh1m.yaml":
+        obj = os.path.join(ROOT, "scenes", "assets", "objects", "grid708.obj")
+        if not os.path.exists(obj):
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_mesh.py"), "grid", "708", obj])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_rate(scene_file, width, height, spp, bounces, threads):
+    """Oracle (CPU restatement of the reference) on `spp` samples of the scene at width x height."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import cudaraytracer_amd as crt
     lib = oracle_lib.load()
-    sc = crt.load_scene(scene_file)
-    sc.set_render(width, height, samples=spp)
+    sc = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
+    sc.set_render(width, height, samples=spp, max_bounces=bounces)
     dp = crt.lib().crt_host_scene_desc(sc._host)
     t0 = time.perf_counter()
     _, stats = oracle_lib.render(lib, dp, width, height, samples=spp, threads=threads)
     dt = time.perf_counter() - t0
     sc.close()
-    return {"value": round(stats["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{os.path.basename(scene_file)} {width}x{height}, {spp} of the spp, all bounces: "
-                      f"{stats['rays']} rays in {dt:.2f} s on {threads} OpenMP threads"}
+    return stats["rays"] / dt / 1e6, stats["rays"], dt
+
+
+def cpu_baseline(scene_file, width, height, spp_all, threads_all):
+    """The oracle timed on this machine's host cores on a bounded sample of the same workload (the
+    full-size image at a reduced sample count): one thread and `threads_all` OpenMP threads, plus
+    the reference's own CPU-sized case (orthographic 256x256, 8 spp, 10 bounces)."""
+    name = os.path.basename(scene_file)
+    v1, rays1, dt1 = oracle_rate(scene_file, width, height, 1, 0, 1)
+    va, raysa, dta = oracle_rate(scene_file, width, height, spp_all, 0, threads_all)
+    ortho = os.path.join(ROOT, "scenes", "orthographic.yaml")
+    o1, orays, odt1 = oracle_rate(ortho, 256, 256, 8, 10, 1)
+    oa, _, odta = oracle_rate(ortho, 256, 256, 8, 10, threads_all)
+    return {"value": round(va, 3), "unit": "Mrays/s", "cores": threads_all, "kind": "port",
+            "threads_1": round(v1, 3), "threads_all": round(va, 3),
+            "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
+            "sample": f"{name} {width}x{height}, all bounces: 1 thread on 1 of the spp ({rays1} rays in {dt1:.2f} s), "
+                      f"{threads_all} OpenMP threads (this job's CPU share of the node's {os.cpu_count()} logical CPUs) on "
+                      f"{spp_all} of the spp ({raysa} rays in {dta:.2f} s)",
+            "config1_orthographic_256x256_8spp_10bounces": {"threads_1": round(o1, 3), "threads_all": round(oa, 3), "rays": orays,
+                                                            "seconds_1": round(odt1, 3), "seconds_all": round(odta, 3)}}
 
 
 def main():
@@ -69,8 +128,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="cornell_box.yaml")
-    ap.add_argument("--cpu-spp", type=int, default=10, help="samples per pixel of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scene", default=HEADLINE)
+    ap.add_argument("--spp", type=int, default=0, help="override the scene's samples per pixel (0 = keep)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the scene's frame divided over the GPUs (default), weak = the scene's spp per GPU")
+    ap.add_argument("--sharding", choices=("auto", "samples", "tiles"), default="auto", help="how a strong-scaling frame is divided")
+    ap.add_argument("--cpu-spp", type=int, default=10, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -102,25 +165,70 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if rank == 0:
+        ensure_assets(args.scene)
+    if distributed:
+        dist.barrier()
     scene_file = os.path.join(ROOT, "scenes", args.scene)
-    sc = crt.load_scene(scene_file)
+    sc = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
+    if args.spp > 0:
+        sc.set_render(samples=args.spp)
     ri = sc.render_info
     W, H, spp, bounces = ri.image_width, ri.image_height, ri.samples_per_pixel, ri.max_bounces
     sc.upload()
-    # Frames in flight: with more than one process the all-reduce of frame k runs while frame k+1
-    # (and the start of k+2) renders, so three sets of pass buffers rotate; a frame's buffers are
-    # rendered into again only after its all-reduce has finished.
-    depth = 3 if distributed else 1
-    passes = [torch.zeros(14 * W * H, dtype=torch.float32, device="cuda") for _ in range(depth)]
-    bufs = [crt.Buffer(W, H, ri.gamma, device_ptr=p.data_ptr()) for p in passes]
     lib = crt.lib()
     dev = sc.get_device_scene()
-    first, count = multi_gpu.rank_sample_range(rank, world, spp)
+
+    # ---- how the frame is divided
+    if not distributed:
+        sharding, first, count, total_spp = "single", 0, spp, spp
+    elif args.scaling == "weak":
+        sharding, total_spp = "samples", spp * world
+        first, count = multi_gpu.rank_sample_range(rank, world, spp)
+    else:
+        total_spp = spp
+        sharding = args.sharding if args.sharding != "auto" else multi_gpu.choose_sharding(W, H, spp, world)
+        if sharding == "samples":
+            first, count = multi_gpu.split_samples(spp, world)[rank]
+            if count == 0:
+                raise SystemExit(f"bench.py: {spp} samples cannot be divided over {world} GPUs; use --sharding tiles")
+        else:
+            first, count = 0, spp
+
+    # Frames in flight: with more than one process the collective of frame k runs while frame k+1
+    # (and the start of k+2) renders, so three sets of buffers rotate; a frame's buffers are
+    # rendered into again only after its collective has finished.
+    depth = 3 if distributed else 1
+    band_rows = multi_gpu.BAND_ROWS
+    if sharding == "tiles":
+        own_rows = crt.band_row_count(H, band_rows, rank, world)
+        stride = multi_gpu.band_stride_floats(W, H, world)
+        own = [torch.zeros(stride, dtype=torch.float32, device="cuda") for _ in range(depth)]
+        gathered = [torch.zeros(world * stride, dtype=torch.float32, device="cuda") for _ in range(depth)]
+        image = torch.zeros(14 * W * H, dtype=torch.float32, device="cuda")
+        bufs = [crt.Buffer(W, own_rows, ri.gamma, device_ptr=t.data_ptr()) for t in own]
+        image_buf = crt.Buffer(W, H, ri.gamma, device_ptr=image.data_ptr())
+    else:
+        passes = [torch.zeros(14 * W * H, dtype=torch.float32, device="cuda") for _ in range(depth)]
+        bufs = [crt.Buffer(W, H, ri.gamma, device_ptr=p.data_ptr()) for p in passes]
+    # the renders run on the scene's own stream: the fills above (torch's stream) must have landed
+    torch.cuda.synchronize()
     pending = [None] * depth
+
+    def start_collective(slot):
+        if not distributed:
+            return
+        if sharding == "tiles":
+            pending[slot] = multi_gpu.gather_bands_async(own[slot], gathered[slot], dist)
+        else:
+            pending[slot] = multi_gpu.combine_means_async(passes[slot], count, total_spp, dist)
 
     def wait_for(slot):
         if pending[slot] is not None:
             pending[slot].wait()
+            if sharding == "tiles":
+                crt.assemble_bands(image_buf, gathered[slot].data_ptr(), stride, band_rows, world,
+                                   stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.current_stream().synchronize()
             pending[slot] = None
 
@@ -132,9 +240,12 @@ def main():
         for k in range(steps):
             slot = k % depth
             wait_for(slot)
-            crt.render_launch(sc, bufs[slot], first, count)
-            if previous is not None and distributed:
-                pending[previous] = multi_gpu.combine_means_async(passes[previous], count, spp * world, dist)
+            if sharding == "tiles":
+                crt.render_bands_launch(sc, bufs[slot], first, count, band_rows, rank, world)
+            else:
+                crt.render_launch(sc, bufs[slot], first, count)
+            if previous is not None:
+                start_collective(previous)
             _, r = crt.render_finish(sc)
             tr, rs = C.c_float(0), C.c_float(0)
             lib.crt_render_timings(dev, C.byref(tr), C.byref(rs))
@@ -142,8 +253,8 @@ def main():
             trace_ms += tr.value
             resolve_ms += rs.value
             previous = slot
-        if previous is not None and distributed:
-            pending[previous] = multi_gpu.combine_means_async(passes[previous], count, spp * world, dist)
+        if previous is not None:
+            start_collective(previous)
         for slot in range(depth):
             wait_for(slot)
         return rays, trace_ms, resolve_ms
@@ -176,26 +287,46 @@ def main():
         value = rays_total / elapsed / 1e6
         rays_per_launch = rays_rank / args.steps
         kernel_ms = trace_ms / args.steps
-        flops = FLOPS_PER_RAY.get(args.scene)
+        flops = flops_per_ray(args.scene)
         roofline = None
         if flops:
+            counts = REFERENCE_COUNTS[args.scene]
             achieved = rays_per_launch * flops / (kernel_ms * 1e-3) / 1e12
-            hbm = rays_per_launch * BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
-            roofline = {"bound": "valu", "kernel": "render_fused", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": measured_traffic(args.scene),
-                        "kernel_ms": round(kernel_ms, 4), "rays_per_launch": int(rays_per_launch),
-                        "flops_per_ray": flops,
-                        "hbm": {"achieved": round(hbm, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(hbm / PEAK_HBM_GBS, 4), "bytes_per_ray": BYTES_PER_RAY}}
+            traffic = measured_traffic(args.scene) if world == 1 and args.spp == 0 else None
+            hbm_achieved = None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "valu", "kernel": "render_fused", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                "kernel_ms": round(kernel_ms, 4), "resolve_ms": round(resolve_ms / args.steps, 4),
+                "rays_per_launch": int(rays_per_launch),
+                "flops_per_ray": round(flops, 1),
+                "flops_model": "reference-algorithm flops: 24*N_box + 84*N_prim + 60*N_accept + 100 with the counts of the "
+                               "reference's own traversal (oracle, reduced image size), not the instructions these kernels issue",
+                "reference_counts_per_ray": {"node_pops": counts[0], "box_tests": counts[1], "prim_tests": counts[2], "accepts": counts[3]},
+                "hbm": {"achieved": None if hbm_achieved is None else round(hbm_achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": None if hbm_achieved is None else round(hbm_achieved / PEAK_HBM_GBS, 5),
+                        "source": "measured: FETCH_SIZE + WRITE_SIZE of the kernel (profiles/traffic.json) / kernel_ms",
+                        "modelled_wavefront_equivalent": {
+                            "bytes_per_ray": STATE_BYTES_PER_RAY,
+                            "GB/s": round(rays_per_launch * STATE_BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9, 1),
+                            "note": "state a multi-kernel wavefront tracer would move through HBM per ray; the fused kernel keeps it in registers",
+                            "scene_bytes_per_ray_reference_walk": round(128.0 * counts[0] + 48.0 * counts[2], 1)}}}
+        if not distributed:
+            how = "single GPU"
+        elif sharding == "tiles":
+            how = (f"image tiles: bands of {band_rows} rows round-robin over {world} ranks, all samples per rank, one all-gather of "
+                   f"14*W*H floats + assemble kernel per frame, overlapped with the next frame")
+        else:
+            how = (f"sample ranges per rank ({args.scaling}), one all-reduce of 14*W*H floats per frame, overlapped with the next frame")
         out = {
-            "metric": "Mrays/s (whole node) Cornell box 1000x1000, 50spp, 15 bounces" if args.scene == "cornell_box.yaml"
+            "metric": "Mrays/s (whole node) Cornell box 1000x1000, 50spp, 15 bounces" if args.scene == HEADLINE and args.spp == 0
                       else f"Mrays/s (whole node) {args.scene}",
             "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak" if (distributed and args.scaling == "weak") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H}, {spp} spp per GPU, {bounces} bounces",
-                       "sharding": "sample ranges per rank, one all-reduce of 14*W*H floats per frame, overlapped with the next frame" if world > 1 else "single GPU",
-                       "rays_per_step": rays_total // args.steps},
+            "config": {"workload": f"{args.scene} {W}x{H}, {total_spp} spp in total, {bounces} bounces",
+                       "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps},
             "roofline": roofline,
         }
         if world == 1 and args.cpu_spp > 0:

@@ -106,6 +106,11 @@ SIGNATURES = {
     "crt_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_render_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "crt_render_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "crt_band_row_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crt_render_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_uint64)]),
+    "crt_render_bands_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crt_buffers_assemble_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "crt_scene_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "crt_render_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "crt_render_finish": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),

@@ -348,6 +348,34 @@ def render_range(scene, buf, first_sample, samples):
     return secs.value, rays.value
 
 
+def band_row_count(height, band_rows, band_index, band_count):
+    """Rows of an image of `height` rows owned by band `band_index` of `band_count` (crt_band_row_count)."""
+    return _check(_lib.crt_band_row_count(int(height), int(band_rows), int(band_index), int(band_count)))
+
+
+def render_bands(scene, own, first_sample, samples, band_rows, band_index, band_count):
+    """Tile split over GPUs: all samples of the rows band `band_index` owns, into `own` (a Buffer
+    of band_row_count() rows).  Returns (seconds, rays)."""
+    secs = C.c_float(0)
+    rays = C.c_uint64(0)
+    _check(_lib.crt_render_bands(scene.get_device_scene(), own.get_device_buffer(), first_sample, samples, band_rows,
+                                 band_index, band_count, C.byref(secs), C.byref(rays)))
+    return secs.value, rays.value
+
+
+def render_bands_launch(scene, own, first_sample, samples, band_rows, band_index, band_count):
+    """render_bands without waiting (finish with render_finish)."""
+    _check(_lib.crt_render_bands_launch(scene.get_device_scene(), own.get_device_buffer(), first_sample, samples,
+                                        band_rows, band_index, band_count))
+
+
+def assemble_bands(full, gathered_ptr, rank_stride_floats, band_rows, band_count, stream=None):
+    """Whole image from the all-gathered band buffers (crt_buffers_assemble_bands), asynchronously on
+    `stream` (a hipStream_t as int, None = the default stream)."""
+    _check(_lib.crt_buffers_assemble_bands(full.get_device_buffer(), C.c_void_p(gathered_ptr), rank_stride_floats,
+                                           band_rows, band_count, C.c_void_p(stream or 0)))
+
+
 def render_launch(scene, buf, first_sample, samples):
     """Starts render_range on the scene's stream without waiting (crt_render_launch)."""
     _check(_lib.crt_render_launch(scene.get_device_scene(), buf.get_device_buffer(), first_sample, samples, 0))

@@ -62,7 +62,17 @@ struct RenderArgs {
     int first_sample, samples, chunk_size, chunks;
     int prim_batch;                  // tree modes: lanes with leaf candidates that trigger a round of primitive tests
     int ready_percent;               // tree modes: shade once this share of the wave's rays has finished its walk
+    // Row bands (multi-GPU tile sharding): the launch covers the tile rows g with
+    // (g / band_tiles) % band_count == band_index; tiles_y counts only those.  A launch of the whole
+    // image has band_tiles = tiles_y, band_count = 1, band_index = 0.
+    int band_tiles, band_index, band_count;
 };
+
+// Tile row of the image for the l-th tile row of a band launch.
+__device__ __forceinline__ int band_global_tile_row(int l, int band_tiles, int band_index, int band_count) {
+    const int b = l / band_tiles;
+    return (b * band_count + band_index) * band_tiles + (l - b * band_tiles);
+}
 
 // Cooperative copy of the traversal data HBM -> LDS (field-major, see SceneLds).
 __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int nn, const float4* prims, int no,
@@ -176,7 +186,8 @@ __global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused
         w.valid = q < (unsigned int)item_count;
         w.chunk = (int)(q / (unsigned int)A.ntiles);
         w.tile = (int)q - w.chunk * A.ntiles;
-        w.tx = w.tile % A.tiles_x; w.ty = w.tile / A.tiles_x;
+        w.tx = w.tile % A.tiles_x;
+        w.ty = band_global_tile_row(w.tile / A.tiles_x, A.band_tiles, A.band_index, A.band_count);
         w.s0 = A.first_sample + w.chunk * A.chunk_size;
         const int s1 = min(w.s0 + A.chunk_size, A.first_sample + A.samples);
         w.total = w.valid ? (s1 - w.s0) * kTilePixels : 0;
@@ -367,6 +378,7 @@ struct ResolveArgs {
     int width, height, tiles_x, tile_rows, ntiles, pix_padded, chunks;
     float done, count;     // samples already in the buffers / samples summed now
     int fold;              // 0: overwrite with sum/count, 1: (old*done + sum)/(done+count)
+    int band_tiles, band_index, band_count;   // as in RenderArgs; the pass arrays hold the band's rows only
 };
 
 __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
@@ -374,9 +386,11 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
     if (t >= R.pix_padded) return;
     const int tile_pixels = kTileW * R.tile_rows;
     const int tile = t / tile_pixels, lane = t - tile * tile_pixels;
-    const int pi = (tile % R.tiles_x) * kTileW + (lane & 7), pj = (tile / R.tiles_x) * R.tile_rows + (lane >> 3);
+    const int local_row = tile / R.tiles_x;
+    const int pi = (tile % R.tiles_x) * kTileW + (lane & 7);
+    const int pj = band_global_tile_row(local_row, R.band_tiles, R.band_index, R.band_count) * R.tile_rows + (lane >> 3);
     if (pi >= R.width || pj >= R.height) return;
-    const int pixel = pj * R.width + pi;
+    const int pixel = (local_row * R.tile_rows + (lane >> 3)) * R.width + pi;    // row within the band's own buffer
     float v[kPasses];
 #pragma unroll
     for (int k = 0; k < kPasses; k++) {
@@ -395,6 +409,38 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
         float x = R.fold ? (*dst[k] * R.done + v[k]) / total : v[k] / R.count;
         *dst[k] = x;
     }
+}
+
+// Multi-GPU tile split: builds the full pass arrays from the ranks' band buffers after an
+// all-gather.  gathered + r * stride holds rank r's six arrays back to back (color, albedo,
+// emission, normal as [rows_r * W][3], depth and opacity as [rows_r * W]) for the rows it owns.
+struct AssembleArgs {
+    const float* gathered;
+    size_t stride;
+    float *color, *albedo, *emission, *normal, *depth, *opacity;
+    int width, height, band_rows, band_count;
+};
+__global__ __launch_bounds__(kBlock) void assemble_bands(AssembleArgs A) {
+    const size_t pixel = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= (size_t)A.width * A.height) return;
+    const int pj = (int)(pixel / A.width), pi = (int)(pixel - (size_t)pj * A.width);
+    const int band = pj / A.band_rows, rank = band % A.band_count;
+    const int local_row = (band / A.band_count) * A.band_rows + (pj - band * A.band_rows);
+    // rows owned by `rank`
+    const int period = A.band_rows * A.band_count;
+    const int whole = A.height / period, rest = A.height - whole * period;
+    const int rows = whole * A.band_rows + min(A.band_rows, max(0, rest - rank * A.band_rows));
+    const size_t n = (size_t)rows * A.width, src = (size_t)local_row * A.width + pi;
+    const float* base = A.gathered + (size_t)rank * A.stride;
+    float* const dst3[4] = {A.color, A.albedo, A.emission, A.normal};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        dst3[k][3 * pixel] = base[3 * (k * n + src)];
+        dst3[k][3 * pixel + 1] = base[3 * (k * n + src) + 1];
+        dst3[k][3 * pixel + 2] = base[3 * (k * n + src) + 2];
+    }
+    A.depth[pixel] = base[12 * n + src];
+    A.opacity[pixel] = base[13 * n + src];
 }
 
 // Bounce-0 closest hit per pixel for the parity tables.
@@ -786,14 +832,28 @@ bool primitives_inside_their_boxes(const crt_scene_desc* d) {
 // one) to a few percent of its length.  `capacity` = bytes of chunk-sum scratch available.
 struct ChunkPlan {
     int tile_h, tiles_x, tiles_y, ntiles, pix_padded, chunk_size, chunks;
+    int band_tiles;        // tile rows per band (whole image: all of them)
     size_t bytes;          // chunk sums of this plan
     bool fits;
 };
-ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacity) {
+// Row bands of a multi-GPU tile split: band `index` of `count` owns the pixel rows j with
+// (j / rows) % count == index.  {0, 0, 1} = the whole image.
+struct Bands {
+    int rows, index, count;
+};
+// Number of pixel rows of an image of `height` rows that the band owns.
+int band_row_count(int height, Bands b) {
+    if (b.count <= 1) return height;
+    const int period = b.rows * b.count;
+    const int full = height / period, rest = height - full * period;
+    return full * b.rows + std::min(b.rows, std::max(0, rest - b.index * b.rows));
+}
+ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacity, Bands bands = {0, 0, 1}) {
     ChunkPlan p;
     p.tile_h = tile_rows(mode);
     p.tiles_x = (sc->dev.width + kTileW - 1) / kTileW;
-    p.tiles_y = (sc->dev.height + p.tile_h - 1) / p.tile_h;
+    p.tiles_y = (band_row_count(sc->dev.height, bands) + p.tile_h - 1) / p.tile_h;
+    p.band_tiles = bands.count <= 1 ? std::max(1, p.tiles_y) : bands.rows / p.tile_h;
     p.ntiles = p.tiles_x * p.tiles_y;
     p.pix_padded = p.ntiles * kTileW * p.tile_h;
     const size_t chunk_bytes = (size_t)kPasses * p.pix_padded * sizeof(float);
@@ -1283,13 +1343,19 @@ struct ScratchView {
     size_t partial_bytes;
 };
 
-static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done, const ScratchView& S, const char* who) {
+static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done, const ScratchView& S, const char* who,
+                         Bands bands = {0, 0, 1}) {
     if (!sc || !buf) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": null argument");
-    if (buf->width != sc->dev.width || buf->height != sc->dev.height) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": buffer size does not match the scene");
+    if (bands.count < 1 || bands.index < 0 || bands.index >= bands.count || (bands.count > 1 && (bands.rows <= 0 || bands.rows % 8 != 0)))
+        return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": band_rows must be a positive multiple of 8 and 0 <= band_index < band_count");
+    const int own_rows = band_row_count(sc->dev.height, bands);
+    if (buf->width != sc->dev.width || buf->height != own_rows)
+        return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": buffer size does not match the scene" + (bands.count > 1 ? " (a band's buffers hold its own " + std::to_string(own_rows) + " rows)" : ""));
+    if (own_rows == 0) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": this band owns no rows of the image");
     if (samples <= 0 || first_sample < 0) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": samples must be positive");
     if (sc->launched) return crt::set_error(CRT_ERR_INVALID, std::string(who) + ": a render is already in flight on this scene");
     CRT_HIP(hipSetDevice(sc->device));
-    const ChunkPlan plan = plan_chunks(sc, kernel_mode(sc), samples, S.partial_bytes);
+    const ChunkPlan plan = plan_chunks(sc, kernel_mode(sc), samples, S.partial_bytes, bands);
     if (!plan.fits)
         return crt::set_error(CRT_ERR_UNSUPPORTED, std::string(who) + ": the chunk sums of this launch (" + std::to_string(sc->opt.deterministic ? (size_t)samples * kPasses * plan.pix_padded * sizeof(float) : (size_t)kPasses * plan.pix_padded * sizeof(float)) +
                                                        " bytes) exceed the scratch available (" + std::to_string(S.partial_bytes) + " bytes)");
@@ -1309,6 +1375,9 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     A.spill_threads = sc->spill_threads;
     A.prim_batch = sc->opt.prim_batch > 0 ? sc->opt.prim_batch : 8;
     A.ready_percent = sc->opt.ready_percent > 0 ? sc->opt.ready_percent : 65;
+    A.band_tiles = plan.band_tiles;
+    A.band_index = bands.index;
+    A.band_count = bands.count;
     A.ray_counter = S.counters;
     A.queue = reinterpret_cast<unsigned int*>(S.counters + 1);
     CRT_HIP(hipMemsetAsync(S.counters, 0, 2 * sizeof(unsigned long long), sc->stream));
@@ -1330,6 +1399,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     R.done = (float)fold_done;
     R.count = (float)samples;
     R.fold = fold_done > 0 ? 1 : 0;
+    R.band_tiles = plan.band_tiles; R.band_index = bands.index; R.band_count = bands.count;
     hipLaunchKernelGGL(resolve_passes, dim3((plan.pix_padded + kBlock - 1) / kBlock), dim3(kBlock), 0, sc->stream, R);
     CRT_HIP(hipGetLastError());
     CRT_HIP(hipEventRecord(sc->ev_stop, sc->stream));
@@ -1344,6 +1414,48 @@ int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int sam
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: null argument");
     const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes};
     return launch_render(sc, buf, first_sample, samples, fold_done, S, "crt_render_launch");
+}
+
+int crt_band_row_count(int height, int band_rows, int band_index, int band_count) {
+    crt::clear_error();
+    if (height < 0 || band_count < 1 || band_index < 0 || band_index >= band_count || (band_count > 1 && (band_rows <= 0 || band_rows % 8 != 0)))
+        return crt::set_error(CRT_ERR_INVALID, "crt_band_row_count: band_rows must be a positive multiple of 8 and 0 <= band_index < band_count");
+    return band_row_count(height, Bands{band_rows, band_index, band_count});
+}
+
+int crt_render_bands_launch(crt_scene* sc, crt_buffers* own, int first_sample, int samples, int band_rows, int band_index, int band_count) {
+    crt::clear_error();
+    if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_bands_launch: null argument");
+    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes};
+    return launch_render(sc, own, first_sample, samples, 0, S, "crt_render_bands_launch", Bands{band_rows, band_index, band_count});
+}
+
+int crt_render_bands(crt_scene* sc, crt_buffers* own, int first_sample, int samples, int band_rows, int band_index, int band_count,
+                     float* seconds_out, uint64_t* rays_out) {
+    int rc = crt_render_bands_launch(sc, own, first_sample, samples, band_rows, band_index, band_count);
+    if (rc != CRT_OK) return rc;
+    float ms = 0.0f;
+    rc = crt_render_finish(sc, &ms, rays_out);
+    if (seconds_out) *seconds_out = ms * 1e-3f;
+    return rc;
+}
+
+int crt_buffers_assemble_bands(crt_buffers* full, const float* gathered, size_t rank_stride_floats, int band_rows, int band_count, void* hip_stream) {
+    crt::clear_error();
+    if (!full || !gathered) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_assemble_bands: null argument");
+    if (band_count < 1 || band_rows <= 0 || band_rows % 8 != 0) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_assemble_bands: band_rows must be a positive multiple of 8");
+    size_t largest = 0;
+    for (int r = 0; r < band_count; r++) largest = std::max(largest, (size_t)band_row_count(full->height, Bands{band_rows, r, band_count}));
+    if (rank_stride_floats < largest * full->width * kPasses) return crt::set_error(CRT_ERR_INVALID, "crt_buffers_assemble_bands: rank stride smaller than the largest band");
+    AssembleArgs A;
+    A.gathered = gathered; A.stride = rank_stride_floats;
+    A.color = full->color(); A.albedo = full->albedo(); A.emission = full->emission(); A.normal = full->normal();
+    A.depth = full->depth(); A.opacity = full->opacity();
+    A.width = full->width; A.height = full->height; A.band_rows = band_rows; A.band_count = band_count;
+    const size_t n = (size_t)full->width * full->height;
+    hipLaunchKernelGGL(assemble_bands, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), A);
+    CRT_HIP(hipGetLastError());
+    return CRT_OK;
 }
 
 int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {

@@ -258,6 +258,27 @@ int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_
 int crt_render_range(crt_scene* sc, crt_buffers* buf, int first_sample, int samples,
                      float* seconds_out, uint64_t* rays_out);
 
+/* Multi-GPU by image tiles instead of sample ranges: the image is cut into bands of `band_rows`
+ * pixel rows (a positive multiple of 8) dealt round-robin to `band_count` ranks; rank
+ * `band_index` owns the rows j with (j / band_rows) % band_count == band_index and renders ALL
+ * samples of those rows.  Its buffers (crt_buffers_create / _wrap with the scene's width and
+ * crt_band_row_count() rows) hold just these rows, top to bottom, in the usual six-array layout,
+ * so a rank's result is one contiguous block that an all-gather can send as it is; there is no
+ * reduction.  Pixels get the same samples as in a single-GPU render (the RNG is keyed by the
+ * pixel's position in the whole image).  crt_render_bands leaves the MEAN of sample numbers
+ * first_sample+1 .. first_sample+samples in `own` like crt_render_range; the _launch form returns
+ * without waiting (finish with crt_render_finish). */
+int crt_band_row_count(int height, int band_rows, int band_index, int band_count);
+int crt_render_bands(crt_scene* sc, crt_buffers* own, int first_sample, int samples,
+                     int band_rows, int band_index, int band_count, float* seconds_out, uint64_t* rays_out);
+int crt_render_bands_launch(crt_scene* sc, crt_buffers* own, int first_sample, int samples,
+                            int band_rows, int band_index, int band_count);
+/* After the all-gather: `gathered` (device memory) holds the band buffers of ranks 0..band_count-1
+ * at gathered + r * rank_stride_floats; writes the whole image into `full`.  Runs on `hip_stream`
+ * (a hipStream_t, NULL = the default stream) without waiting. */
+int crt_buffers_assemble_bands(crt_buffers* full, const float* gathered, size_t rank_stride_floats,
+                               int band_rows, int band_count, void* hip_stream);
+
 /* Asynchronous pieces of crt_render_range for callers that time with their own events:
  * launch on the scene's stream without waiting, then finish (sync + read ray counter).
  * crt_scene_stream returns the hipStream_t as void*. */
