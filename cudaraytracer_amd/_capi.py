@@ -118,6 +118,7 @@ SIGNATURES = {
     "crt_render_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "crt_profile_counters": (C.c_int, [C.c_void_p, C.c_int]),
     "crt_scene_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "crt_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_trace_primary": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "crt_normalize_pass": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "crt_write_image": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]),

@@ -209,6 +209,14 @@ class Scene:
                                       ff.ctypes.data))
         return obj, t, u, v, ff
 
+    def probe(self, kind, cases):
+        """crt_probe: `cases` is a float32 array [n, in_floats(kind)]; returns [n, out_floats(kind)]."""
+        self.upload()
+        cases = np.ascontiguousarray(cases, np.float32)
+        out = np.zeros((cases.shape[0], (1, 11, 3, 7)[kind]), np.float32)
+        _check(_lib.crt_probe(self._dev, kind, cases.shape[0], cases.ctypes.data, out.ctypes.data))
+        return out
+
     def _drop_device(self):
         if self._dev is not None:
             _lib.crt_scene_destroy(self._dev)

@@ -496,6 +496,87 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     }
 }
 
+// Single-function probes for known-answer tests: one thread per case evaluates ONE building block
+// of the path with the same device functions the render kernels call.
+//   kind 0 box      in[14] = min[3] max[3] origin[3] dir[3] tmin tmax      out[1]  = bit 0: slab test as the tree walk
+//                                                                                     writes it, bit 1: as the flat mode does
+//   kind 1 object   in[10] = object origin[3] dir[3] time tmin tmax         out[11] = hit t u v front normal[3] p[3]
+//   kind 2 texture  in[6]  = texture u v p[3]                               out[3]  = colour
+//   kind 3 camera   in[3]  = i j sample                                     out[7]  = origin[3] dir[3] time
+// Integers travel as float bit patterns.
+struct ProbeArgs {
+    DevScene sc;
+    int kind, count;
+    const float* in;
+    float* out;
+};
+__global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs A) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= A.count) return;
+    const DevScene& sc = A.sc;
+    if (A.kind == 0) {
+        const float* in = A.in + (size_t)idx * 14;
+        const V3 mn = v3(in[0], in[1], in[2]), mx = v3(in[3], in[4], in[5]), o = v3(in[6], in[7], in[8]), d = v3(in[9], in[10], in[11]);
+        const float tmin = in[12], tmax = in[13];
+        const V3 inv = slab_reciprocal(d, 0);
+        // tree walk: near / far plane picked by the sign of the reciprocal (tree_run)
+        float t0 = ((inv.x < 0.0f ? mx.x : mn.x) - o.x) * inv.x, t1 = ((inv.x < 0.0f ? mn.x : mx.x) - o.x) * inv.x;
+        float lo = fmaxf(tmin, t0), hi = fminf(tmax, t1);
+        t0 = ((inv.y < 0.0f ? mx.y : mn.y) - o.y) * inv.y; t1 = ((inv.y < 0.0f ? mn.y : mx.y) - o.y) * inv.y;
+        lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+        t0 = ((inv.z < 0.0f ? mx.z : mn.z) - o.z) * inv.z; t1 = ((inv.z < 0.0f ? mn.z : mx.z) - o.z) * inv.z;
+        lo = fmaxf(lo, t0); hi = fminf(hi, t1);
+        int result = !(hi < lo) ? 1 : 0;
+        // flat mode: fmin / fmax of the two plane distances, open upper end (flat_box_hit); only
+        // comparable when tmax is +inf
+        NativeQuad b0 = {mn.x, mx.x, mn.y, mx.y}, b1 = {mn.z, mx.z, 0.0f, 0.0f};
+        const unsigned long long m = flat_box_hit(b0, b1, o, inv, tmin);
+        if ((m >> (threadIdx.x & 63)) & 1ull) result |= 2;
+        A.out[idx] = __int_as_float(result);
+    } else if (A.kind == 1) {
+        const float* in = A.in + (size_t)idx * 10;
+        float* out = A.out + (size_t)idx * 11;
+        const int obj = __float_as_int(in[0]);
+        Ray r;
+        r.o = v3(in[1], in[2], in[3]); r.d = v3(in[4], in[5], in[6]); r.time = in[7];
+        const float tmin = in[8], tmax = in[9];
+        for (int k = 0; k < 11; k++) out[k] = 0.0f;
+        if (obj < 0 || obj >= sc.object_count) return;
+        SceneGlobal S;
+        S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+        const float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
+        const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
+        V3 o = r.o, d = r.d;
+        if (xf >= 0) to_object_space(S.xform(xf), r.o, r.d, o, d);
+        Hit h;
+        h.t = 0.0f; h.obj = obj; h.bu = 0.0f; h.bv = 0.0f;
+        bool ok;
+        if (type == 2) ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, tmax, 0, h.t, h.bu, h.bv);
+        else ok = sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, h.t);
+        if (!ok) return;
+        const Surface sf = make_surface<true>(sc, r, h);
+        out[0] = 1.0f; out[1] = h.t; out[2] = sf.u; out[3] = sf.v; out[4] = sf.front ? 1.0f : 0.0f;
+        out[5] = sf.normal.x; out[6] = sf.normal.y; out[7] = sf.normal.z;
+        out[8] = sf.p.x; out[9] = sf.p.y; out[10] = sf.p.z;
+    } else if (A.kind == 2) {
+        const float* in = A.in + (size_t)idx * 6;
+        const int tex = __float_as_int(in[0]);
+        V3 c = v3(0.0f, 0.0f, 0.0f);
+        if (tex >= 0 && tex < sc.texture_count) c = texture_value(sc, tex, in[1], in[2], v3(in[3], in[4], in[5]));
+        A.out[(size_t)idx * 3] = c.x; A.out[(size_t)idx * 3 + 1] = c.y; A.out[(size_t)idx * 3 + 2] = c.z;
+    } else {
+        const float* in = A.in + (size_t)idx * 3;
+        const int i = __float_as_int(in[0]), j = __float_as_int(in[1]), sample = __float_as_int(in[2]);
+        Rng rng;
+        rng.init(j * sc.width + i, sample);
+        DevCamera cam = sc.cam;
+        cam.needs_time = 1;                                  // the probe always reports the drawn time
+        const Ray r = camera_ray(cam, i, j, rng);
+        float* out = A.out + (size_t)idx * 7;
+        out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z; out[6] = r.time;
+    }
+}
+
 }  // namespace crt
 
 // ====================================================================== host side =======
@@ -1556,6 +1637,32 @@ int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_
     rc = crt_render_finish(sc, &ms, rays_out);
     if (seconds_out) *seconds_out = ms * 1e-3f;
     return rc;
+}
+
+int crt_probe(crt_scene* sc, int kind, int count, const float* in, float* out) {
+    crt::clear_error();
+    static const int in_floats[4] = {14, 10, 6, 3}, out_floats[4] = {1, 11, 3, 7};
+    if (!sc || !in || !out) return crt::set_error(CRT_ERR_INVALID, "crt_probe: null argument");
+    if (kind < 0 || kind > 3 || count < 0) return crt::set_error(CRT_ERR_INVALID, "crt_probe: kind must be 0..3 and count >= 0");
+    if (count == 0) return CRT_OK;
+    CRT_HIP(hipSetDevice(sc->device));
+    const size_t in_bytes = (size_t)count * in_floats[kind] * sizeof(float), out_bytes = (size_t)count * out_floats[kind] * sizeof(float);
+    void* mem = nullptr;
+    CRT_HIP(hipMalloc(&mem, in_bytes + out_bytes));
+    ProbeArgs A;
+    A.sc = sc->dev; A.kind = kind; A.count = count;
+    A.in = static_cast<const float*>(mem);
+    A.out = reinterpret_cast<float*>(static_cast<unsigned char*>(mem) + in_bytes);
+    hipError_t e = hipMemcpy(mem, in, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, sc->stream, A);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, A.out, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(mem);
+    if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_probe: ") + hipGetErrorString(e));
+    return CRT_OK;
 }
 
 int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t, float* u, float* v, int32_t* front_face) {

@@ -317,6 +317,18 @@ int crt_scene_describe(crt_scene* sc, char* text, int size);
 int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t, float* u,
                       float* v, int32_t* front_face);
 
+/* Single-function probes used by the known-answer tests: `count` cases of ONE building block of
+ * the path, evaluated on the device by the functions the render kernels call.  Host arrays;
+ * integers travel as float bit patterns.
+ *   CRT_PROBE_BOX      aabb::hit (aabb.cuh:132-156)  in[14] = min[3] max[3] origin[3] dir[3] tmin tmax
+ *                      out[1]: bit 0 = the tree walk's form of the test, bit 1 = the flat mode's (tmax ignored)
+ *   CRT_PROBE_OBJECT   hittable::hit (hittable.cuh:426-446)  in[10] = object origin[3] dir[3] time tmin tmax
+ *                      out[11] = hit t u v front_face normal[3] p[3]   (normal after the normal map)
+ *   CRT_PROBE_TEXTURE  _texture::value (texture.cuh:313-324)  in[6] = texture u v p[3]   out[3] = colour
+ *   CRT_PROBE_CAMERA   camera::get_ray (camera.cuh:269-278)   in[3] = i j sample         out[7] = origin[3] dir[3] time */
+enum { CRT_PROBE_BOX = 0, CRT_PROBE_OBJECT = 1, CRT_PROBE_TEXTURE = 2, CRT_PROBE_CAMERA = 3 };
+int crt_probe(crt_scene* sc, int kind, int count, const float* in, float* out);
+
 /* save_passes() (buffer.cuh:165-195): normalise the passes to 8 bit exactly like
  * normalize_* (buffer.cuh:202-318) from HOST float arrays.  `out` = W*H*3 bytes.
  * pass: 0 color 1 albedo 2 emission 3 normal 4 depth 5 opacity. */

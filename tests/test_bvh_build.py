@@ -69,3 +69,30 @@ def test_tree_invariants(crt):
         sub = slice(4 * c, 4 * c + 4)
         live = ~((ch[sub] < 0) & (oi[sub] < 0))
         assert np.all(mn[s] <= mn[sub][live].min(axis=0)) and np.all(mx[s] >= mx[sub][live].max(axis=0))
+
+
+# Per-ray work of the reference's own traversal (bvh.cuh:380-421: node pops, box tests, primitive
+# tests, accepted hits) and its deepest stack, measured on a host run of the reference with another
+# RNG and recorded in the survey of the reference.  They depend on the SHAPE and ORDER of the tree
+# (which boxes sit above which, what is visited first), not only on its root: a builder that
+# sorted or split differently would move them by far more than the Monte-Carlo noise of the paths.
+REFERENCE_TRAVERSAL = [
+    # scene, width, height, spp, bounces, rays/path, pops, box tests, prim tests, accepts, max stack
+    ("orthographic.yaml", 256, 256, 8, 10, 1.310, 2.81, 11.24, 1.02, 0.50, 4),
+    ("cornell_box.yaml", 250, 250, 16, 15, 5.81, 7.75, 30.98, 2.53, 1.00, 7),
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces,rpp,pops,boxes,prims,accepts,max_stack", REFERENCE_TRAVERSAL)
+def test_traversal_statistics_match_values_measured_on_the_reference(crt, oracle, name, w, h, spp, bounces, rpp, pops, boxes, prims, accepts, max_stack):
+    sc = crt.load_scene(scene_path(name))
+    sc.set_render(w, h, samples=spp, max_bounces=bounces)
+    _, st = oracle_lib.render(oracle, crt.lib().crt_host_scene_desc(sc._host), w, h, samples=spp, threads=4)
+    rays = st["rays"]
+    assert st["max_stack"] == max_stack
+    assert abs(rays / (w * h * spp) - rpp) <= 0.01 * rpp
+    assert abs(st["node_pops"] / rays - pops) <= 0.01 * pops
+    assert abs(st["box_tests"] / rays - boxes) <= 0.01 * boxes
+    assert abs(st["prim_tests"] / rays - prims) <= 0.01 * prims + 0.005
+    assert abs(st["accepts"] / rays - accepts) <= 0.01 * accepts + 0.005
+    sc.close()

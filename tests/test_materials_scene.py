@@ -89,3 +89,43 @@ def test_gpu_vs_oracle_small(crt, oracle, mode):
         assert abs(a[m].mean() - b[m].mean()) <= 0.01 * abs(b[m].mean()) + 1e-6, k
     buf.close()
     sc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_vs_oracle_materials_with_hdr_environment(crt, oracle):
+    """materials_hdr.yaml = materials.yaml under an HDR environment image (the configuration
+    "materials.yaml ... with HDR env texture"): besides the sphere uv/tangent, every escaping path
+    goes through acosf/atan2f and an image fetch (render.cuh:76-91).  Same per-sample bound as the
+    black-environment scene; the path structure (ray count) does not depend on the environment's
+    colour, and the environment must show."""
+    crt.set_image_loader(None)
+    w, h, spp = 500, 100, 8
+    images, rays = {}, {}
+    from cudaraytracer_amd import api
+    for name in ("materials.yaml", "materials_hdr.yaml"):
+        sc = crt.load_scene(scene_path(name), base_dir=os.path.join(ROOT, "scenes"))
+        sc.set_render(w, h, samples=spp)
+        assert (sc.desc.textures[sc.desc.background_index].type == 2) == (name == "materials_hdr.yaml")
+        buf = crt.create_buffer(sc)
+        crt.render(sc, buf)
+        images[name], rays[name] = buf.download(), api.last_ray_count
+        if name == "materials_hdr.yaml":
+            oracle.oracle_set_pow5_mulchain(1)
+            try:
+                ref, stats = oracle_lib.render(oracle, crt.lib().crt_host_scene_desc(sc._host), w, h)
+            finally:
+                oracle.oracle_set_pow5_mulchain(0)
+        buf.close()
+        sc.close()
+    got = images["materials_hdr.yaml"]
+    assert abs(rays["materials_hdr.yaml"] - stats["rays"]) <= 2e-4 * stats["rays"]
+    assert rays["materials_hdr.yaml"] == rays["materials.yaml"]
+    for k in ("albedo", "emission", "normal", "depth", "opacity", "color"):
+        a, b = got[k], ref[k]
+        close = np.isclose(a, b, rtol=1e-4, atol=1e-5, equal_nan=True)
+        assert close.mean() > 0.97, (k, close.mean())
+        m = ~(np.isnan(a) | np.isnan(b))
+        assert abs(a[m].mean() - b[m].mean()) <= 0.01 * abs(b[m].mean()) + 1e-6, k
+    # the sky is seen directly around the box and in the metal spheres: brighter than the black variant
+    assert got["color"].mean() > images["materials.yaml"]["color"].mean() + 0.01
+    assert np.array_equal(np.isnan(got["depth"]), np.isnan(images["materials.yaml"]["depth"]))
