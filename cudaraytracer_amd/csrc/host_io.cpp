@@ -26,13 +26,6 @@ std::mutex g_loader_mutex;
 crt_image_loader_fn g_loader = nullptr;
 void* g_loader_user = nullptr;
 
-bool ends_with_ci(const std::string& s, const char* suffix) {
-    size_t n = std::strlen(suffix);
-    if (s.size() < n) return false;
-    for (size_t i = 0; i < n; i++)
-        if (std::tolower((unsigned char)s[s.size() - n + i]) != suffix[i]) return false;
-    return true;
-}
 
 bool read_file(const std::string& path, std::vector<uint8_t>& data) {
     std::ifstream f(path, std::ios::binary);
@@ -53,6 +46,13 @@ int paeth(int a, int b, int c) {
     if (pb <= pc) return b;
     return c;
 }
+// Largest image side the decoders accept (stb_image's STBI_MAX_DIMENSIONS): a header that claims
+// more is rejected before anything is allocated.
+constexpr int kMaxImageSide = 1 << 24;
+bool plausible_size(long long w, long long h) {
+    return w > 0 && h > 0 && w <= kMaxImageSide && h <= kMaxImageSide && w * h <= (1ll << 30);
+}
+
 bool decode_png(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::vector<uint8_t>& out, std::string& err) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) { err = "not a PNG file"; return false; }
@@ -66,6 +66,8 @@ bool decode_png(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::
         if (pos + 12 + len > file.size()) { err = "truncated PNG"; return false; }
         const uint8_t* body = &file[pos + 8];
         if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) { err = "bad PNG header"; return false; }
+            if (!plausible_size(be32(body), be32(body + 4))) { err = "PNG dimensions out of range"; return false; }
             w = (int)be32(body); h = (int)be32(body + 4);
             bit_depth = body[8]; color_type = body[9]; interlace = body[12];
             have_ihdr = true;
@@ -178,12 +180,16 @@ bool decode_pnm(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::
         while (pos < file.size() && std::isspace(file[pos])) pos++;
         if (pos < file.size() && file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; continue; }
         int v = 0; bool any = false;
-        while (pos < file.size() && std::isdigit(file[pos])) { v = v * 10 + (file[pos] - '0'); pos++; any = true; }
+        while (pos < file.size() && std::isdigit(file[pos])) {
+            if (v > kMaxImageSide) { err = "PNM header value out of range"; return false; }
+            v = v * 10 + (file[pos] - '0'); pos++; any = true;
+        }
         if (!any) break;
         vals[got++] = v;
     }
     if (got < 3 || vals[2] != 255) { err = "unsupported PNM header"; return false; }
     pos++;   // single whitespace after maxval
+    if (!plausible_size(vals[0], vals[1])) { err = "PNM dimensions out of range"; return false; }
     w = vals[0]; h = vals[1];
     size_t n = (size_t)w * h * ch;
     if (pos + n > file.size()) { err = "truncated PNM"; return false; }
@@ -215,6 +221,7 @@ bool decode_hdr(const std::vector<uint8_t>& file, float gamma, float scale, int&
     if (!format_ok) { err = "unsupported HDR format"; return false; }
     getline(line);
     if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) { err = "unsupported HDR orientation"; return false; }
+    if (!plausible_size(w, h)) { err = "HDR dimensions out of range"; return false; }
     std::vector<float> img((size_t)w * h * 3);
     auto convert = [&](size_t pix, const uint8_t* rgbe) {
         if (rgbe[3] != 0) {
@@ -436,10 +443,12 @@ bool load_image_file(const std::string& path, float hdr_gamma, float hdr_scale, 
         ok = decode_jpeg(file, (desired_channels >= 1 && desired_channels <= 4) ? desired_channels : 0, width, height, native, got, pixels, error);
         channels = got;
     }
-    else if (ends_with_ci(path, ".png")) ok = decode_png(file, width, height, channels, pixels, error);
-    else if (ends_with_ci(path, ".hdr")) ok = decode_hdr(file, hdr_gamma, hdr_scale, width, height, channels, pixels, error);
-    else if (ends_with_ci(path, ".ppm") || ends_with_ci(path, ".pgm")) ok = decode_pnm(file, width, height, channels, pixels, error);
-    else { error = "no built-in decoder for this file type (install one with crt_set_image_loader)"; return false; }
+    // the format is told from the file's first bytes, like stb_image does, not from its name
+    else if (file.size() >= 8 && !std::memcmp(file.data(), "\x89PNG\r\n\x1a\n", 8)) ok = decode_png(file, width, height, channels, pixels, error);
+    else if (file.size() >= 6 && (!std::memcmp(file.data(), "#?RADIANCE", std::min<size_t>(10, file.size())) || !std::memcmp(file.data(), "#?RGBE", 6)))
+        ok = decode_hdr(file, hdr_gamma, hdr_scale, width, height, channels, pixels, error);
+    else if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) ok = decode_pnm(file, width, height, channels, pixels, error);
+    else { error = "no built-in decoder for this file type (PNG, JPEG, Radiance HDR and binary PGM/PPM are built in; stb_image's BMP, TGA, GIF, PSD and PIC are not: install a decoder with crt_set_image_loader)"; return false; }
     if (!ok) return false;
     if (desired_channels >= 1 && desired_channels <= 4 && desired_channels != channels) {
         convert_channels(pixels, width, height, channels, desired_channels);
@@ -477,8 +486,12 @@ int crt_load_image(const char* filename, float hdr_gamma, float hdr_scale, int d
     if (!filename || !width || !height || !channels || !pixels) return crt::set_error(CRT_ERR_INVALID, "crt_load_image: null argument");
     std::vector<uint8_t> px;
     std::string err;
-    if (!crt::load_image_file(filename, hdr_gamma, hdr_scale, desired_channels, flip_y != 0, *width, *height, *channels, px, err))
-        return crt::set_error(CRT_ERR_IO, std::string("crt_load_image: ") + filename + ": " + err);
+    try {                                                    // no exception may cross the C boundary
+        if (!crt::load_image_file(filename, hdr_gamma, hdr_scale, desired_channels, flip_y != 0, *width, *height, *channels, px, err))
+            return crt::set_error(CRT_ERR_IO, std::string("crt_load_image: ") + filename + ": " + err);
+    } catch (const std::exception& e) {
+        return crt::set_error(CRT_ERR_IO, std::string("crt_load_image: ") + filename + ": " + e.what());
+    }
     *pixels = static_cast<uint8_t*>(std::malloc(px.size() ? px.size() : 1));
     if (!*pixels) return crt::set_error(CRT_ERR_IO, "crt_load_image: out of memory");
     std::memcpy(*pixels, px.data(), px.size());

@@ -819,15 +819,42 @@ bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
     } else {
         dir = std::max(dir, len(c.w));
     }
-    for (int i = 0; i < d->material_count; i++)
-        if (d->materials[i].type == CRT_MAT_METAL) dir = std::max(dir, 1.0 + std::fabs((double)d->materials[i].fuzz));
-    double rot = 1.0, edges = 0.0;
+    // Longest surface normal a scatter can see.  Normal-mapped and smooth-shaded normals are
+    // normalised on the device; a flat triangle's normal is whatever the description holds; a
+    // sphere's is (p - centre) / radius, about 1 but with the rounding error of p, which is
+    // relative to the size of the coordinates, divided by the radius.
+    double normal = 1.0, rot = 1.0, edges = 0.0;
     for (int i = 0; i < d->object_count; i++) {
         const crt_object& o = d->objects[i];
         double f = 0.0;
         for (int k = 0; k < 9; k++) f += (double)o.rotation_inv[k] * o.rotation_inv[k];
         rot = std::max(rot, std::sqrt(f));
-        if (o.type == CRT_OBJ_TRI) edges = std::max(edges, len(o.p1) * len(o.p2));
+        double g = 0.0;
+        for (int k = 0; k < 9; k++) g += (double)o.rotation[k] * o.rotation[k];
+        const double rot_fwd = std::max(1.0, std::sqrt(g));         // normals are rotated to world space
+        if (o.type == CRT_OBJ_TRI) {
+            edges = std::max(edges, len(o.p1) * len(o.p2));
+            if (o.normal_idx < 0 && !o.shade_smooth) normal = std::max(normal, len(o.n0) * rot_fwd);
+        } else if (o.normal_idx < 0) {
+            const double radius = std::fabs((double)o.p2[0]);
+            if (!(radius > 0.0)) return false;
+            const double reach = len(o.p0) + len(o.p1) + radius + len(o.anchor) + len(o.translation);
+            normal = std::max(normal, (1.0 + 4e-6 * reach / radius) * rot_fwd);
+        }
+    }
+    // |v - 2 (v.n) n| for a unit v
+    const double reflected = 1.0 + 2.0 * normal * normal;
+    dir = std::max(dir, normal + 1.0);                               // lambertian: normal + unit vector
+    for (int i = 0; i < d->material_count; i++) {
+        const crt_material& m = d->materials[i];
+        if (m.type == CRT_MAT_METAL) dir = std::max(dir, reflected + std::fabs((double)m.fuzz));
+        if (m.type == CRT_MAT_DIELECTRIC) {
+            const double ior = std::fabs((double)m.ior);
+            if (!(ior > 0.0) || !std::isfinite(ior)) return false;
+            const double ratio = std::max(ior, 1.0 / ior);
+            const double perp = ratio * (1.0 + normal);              // ratio * (uv + cos * n), |cos| <= 1
+            dir = std::max(dir, std::max(reflected, perp + (1.0 + perp) * normal));   // + sqrt(|1 - perp^2|) * n
+        }
     }
     const double dir_object = dir * rot;
     return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p90 && edges * dir_object < 0x1p99;
@@ -979,7 +1006,17 @@ int crt_scene_options_init(crt_scene_options* options) {
 
 int crt_scene_create(const crt_scene_desc* d, crt_scene** out) { return crt_scene_create_ex(d, nullptr, out); }
 
+static int scene_create(const crt_scene_desc* d, const crt_scene_options* options, crt_scene** out);
+
 int crt_scene_create_ex(const crt_scene_desc* d, const crt_scene_options* options, crt_scene** out) {
+    try {                                                    // no exception may cross the C boundary
+        return scene_create(d, options, out);
+    } catch (const std::exception& e) {
+        return crt::set_error(CRT_ERR_INVALID, std::string("crt_scene_create: ") + e.what());
+    }
+}
+
+static int scene_create(const crt_scene_desc* d, const crt_scene_options* options, crt_scene** out) {
     crt::clear_error();
     if (!d || !out) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: null argument");
     crt_scene_options opt;
@@ -1226,12 +1263,16 @@ int crt_scene_create_ex(const crt_scene_desc* d, const crt_scene_options* option
     }
 
     crt_scene* sc = new crt_scene();
-    if (hipGetDevice(&sc->device) != hipSuccess) { delete sc; return crt::set_error(CRT_ERR_DEVICE, "crt_scene_create: no HIP device"); }
+    struct Guard {                                           // frees the half-built scene on every early exit, thrown or returned
+        crt_scene* sc;
+        ~Guard() { if (sc) free_scene(sc); }
+    } guard{sc};
+    if (hipGetDevice(&sc->device) != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, "crt_scene_create: no HIP device");
     if (hipDeviceGetAttribute(&sc->cu_count, hipDeviceAttributeMultiprocessorCount, sc->device) != hipSuccess || sc->cu_count <= 0) sc->cu_count = 256;
 #define CRT_HIP_OR_FREE(call)                                                                                          \
     do {                                                                                                               \
         hipError_t e_ = (call);                                                                                        \
-        if (e_ != hipSuccess) { free_scene(sc); return crt::set_error(CRT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } \
+        if (e_ != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));                     \
     } while (0)
     CRT_HIP_OR_FREE(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
     CRT_HIP_OR_FREE(static_scratch_address(sc->device, &sc->static_scratch));
@@ -1328,9 +1369,10 @@ int crt_scene_create_ex(const crt_scene_desc* d, const crt_scene_options* option
         sc->partial_bytes = std::max(worst.bytes, worst_flat.bytes);
         hipError_t e = hipMalloc((void**)&sc->partial, sc->partial_bytes);
         if (e == hipSuccess) e = hipHostMalloc((void**)&sc->host_counter, sizeof(unsigned long long), hipHostMallocDefault);
-        if (e != hipSuccess) { free_scene(sc); return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: scratch allocation: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: scratch allocation: ") + hipGetErrorString(e));
         *sc->host_counter = 0;
     }
+    guard.sc = nullptr;
     *out = sc;
     return CRT_OK;
 }

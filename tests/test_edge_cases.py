@@ -200,3 +200,31 @@ def test_render_from_another_thread(crt):
         x.close()
     sc.close()
     other.close()
+
+
+@pytest.mark.gpu
+def test_deterministic_option_makes_bulk_renders_bit_reproducible(crt):
+    """A bulk call sums the samples of a chunk in the order their paths finish, so with several
+    samples per chunk (any full-size frame) two runs agree only up to float summation order.
+    crt_scene_options.deterministic renders one sample per chunk and adds the chunks in sample
+    order: two runs of the full-size frame then agree in every bit, and the result equals the
+    default render to that summation-order tolerance."""
+    images = {}
+    for deterministic in (1, 0):
+        sc = crt.load_scene(scene_path("cornell_box.yaml"), base_dir=scene_path(""))
+        sc.set_render(1000, 1000, samples=12)
+        sc.set_options(deterministic=deterministic)
+        buf = crt.create_buffer(sc)
+        runs = []
+        for _ in range(2):
+            crt.render(sc, buf)
+            runs.append(buf.download())
+        images[deterministic] = runs
+        buf.close()
+        sc.close()
+    for k in oracle_lib.PASSES:
+        a, b = images[1]
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        c = images[0][0]
+        np.testing.assert_allclose(c[k], a[k], rtol=2e-5, atol=1e-6, equal_nan=True, err_msg=k)
+        np.testing.assert_allclose(images[0][1][k], a[k], rtol=2e-5, atol=1e-6, equal_nan=True, err_msg=k)

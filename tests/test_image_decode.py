@@ -220,3 +220,37 @@ def test_png_interlaced_and_colour_key(crt, tmp_path):
     got = crt.load_image(path)
     assert got.shape == (h, w, 4) and (got[:, :, :3] == rgb).all()
     assert ((got[:, :, 3] == 0) == (rgb == key).all(-1)).all() and got[3, 4, 3] == 0
+
+
+def test_hostile_headers_are_rejected_without_allocating(crt, tmp_path):
+    """Image files are untrusted input: absurd dimensions, a short IHDR and negative HDR sizes come
+    back as errors through the C boundary (nothing is allocated from a header's claim, nothing is
+    thrown across it), and the format is told from the file's first bytes, not from its name."""
+    import struct
+    import zlib
+    from PIL import Image
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+    sig = b"\x89PNG\r\n\x1a\n"
+    huge = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"")) + chunk(b"IEND", b"")
+    short = sig + chunk(b"IHDR", struct.pack(">II", 4, 4)) + chunk(b"IEND", b"")
+    cases = {"huge.png": huge, "short.png": short,
+             "neg.hdr": b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y -5 +X 7\n" + b"\0" * 64,
+             "big.hdr": b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n",
+             "big.ppm": b"P6\n99999999999 3\n255\n" + b"\0" * 16,
+             "big2.ppm": b"P6\n70000 70000\n255\n" + b"\0" * 16}
+    for name, data in cases.items():
+        path = tmp_path / name
+        path.write_bytes(data)
+        with pytest.raises(crt.CrtError):
+            crt.load_image(str(path))
+    # a PNG behind another name decodes (content sniffing, like stbi_load)
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    Image.fromarray(img, "RGB").save(tmp_path / "real.png")
+    os.rename(tmp_path / "real.png", tmp_path / "texture.tex")
+    assert np.array_equal(crt.load_image(str(tmp_path / "texture.tex")), img)
+    (tmp_path / "unknown.bmp").write_bytes(b"BM" + b"\0" * 60)
+    with pytest.raises(crt.CrtError, match="BMP, TGA, GIF, PSD"):
+        crt.load_image(str(tmp_path / "unknown.bmp"))
