@@ -34,6 +34,9 @@ namespace crt {
 #ifndef CRT_FUSED_WAVES_PER_SIMD
 #define CRT_FUSED_WAVES_PER_SIMD 4    // register budget of render_fused: 512 / 4 = 128 VGPRs
 #endif
+#ifndef CRT_TREE_WAVES_PER_SIMD
+#define CRT_TREE_WAVES_PER_SIMD CRT_FUSED_WAVES_PER_SIMD   // the same for the tree-walk variants
+#endif
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
@@ -42,6 +45,7 @@ constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth o
 // LDS per wave, which there buys a fourth resident block per CU next to the traversal stacks).
 constexpr int kTileW = 8;
 constexpr int tile_rows(int mode) { return mode == 2 ? 8 : 4; }
+constexpr int waves_per_simd(int mode) { return mode == 2 ? CRT_FUSED_WAVES_PER_SIMD : CRT_TREE_WAVES_PER_SIMD; }
 
 // How a kernel reaches the scene geometry
 enum : int {
@@ -139,7 +143,7 @@ struct WorkItem {
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
 template <int MODE, int STACK, int GROUPS, int FAST>
-__global__ __launch_bounds__(kBlock, CRT_FUSED_WAVES_PER_SIMD) void render_fused(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(RenderArgs A) {
     constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
     constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
     extern __shared__ float4 smem[];
@@ -1305,7 +1309,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
     sc->spill_entries = std::max(0, need - stack_entries);
-    sc->spill_threads = std::max(sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves), 1024) * kBlock;
+    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(CRT_FUSED_WAVES_PER_SIMD, CRT_TREE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
         CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
     }
@@ -1506,7 +1510,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     CRT_HIP(hipMemsetAsync(S.counters, 0, 2 * sizeof(unsigned long long), sc->stream));
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
     const long long items = (long long)plan.ntiles * plan.chunks;
-    int resident = sc->cu_count * (4 * CRT_FUSED_WAVES_PER_SIMD / kWaves);   // 4 SIMDs per CU
+    int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc)) / kWaves);   // 4 SIMDs per CU
     if (sc->opt.blocks > 0) resident = std::min(sc->spill_threads / kBlock, sc->opt.blocks);
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
