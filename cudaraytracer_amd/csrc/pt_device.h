@@ -229,11 +229,18 @@ struct SceneLds {
 // flat load that ends up in LDS takes the long way round through the vector-memory path - on
 // every pop of the walk.
 typedef int __attribute__((address_space(3))) * LdsIntPtr;
+typedef float __attribute__((address_space(3))) * LdsFloatPtr;
 typedef int __attribute__((address_space(1))) * GlobalIntPtr;
 struct LaneStack {
     LdsIntPtr base;
     int stride;
     int lds_entries;
+    // Slot codes and box entry distances of the node whose leaf candidates are pending: lane l's
+    // slot i at code[i * stride] / entry[i * stride].  Written once per node with leaf hits and read
+    // once per candidate, they sit in LDS (8 words per lane) instead of eight registers that would
+    // be live across the whole path loop.
+    LdsIntPtr code;
+    LdsFloatPtr entry;
     GlobalIntPtr spill;
     size_t spill_stride;
     __device__ __forceinline__ void put(int e, int v) {
@@ -352,15 +359,12 @@ __device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, flo
 struct TreeState {
     int node, sp;                       // next node to visit as a stack entry: index*2 + leafy (-1: none left), stack height
     unsigned leaf_mask;                 // pending leaf slots of the last visited node
-    int c0, c1, c2, c3;                 // its slot codes
-    float l0, l1, l2, l3;               // and box entry distances
+                                        // (its slot codes and box entry distances: LaneStack::code, ::entry)
     Hit best;                           // best.obj = visiting rank while walking
     int best_obj;                       // object index of the best candidate
     bool best_tri;
     __device__ __forceinline__ void begin(float tmax, int root_entry) {
         node = root_entry; sp = 0; leaf_mask = 0;
-        c0 = c1 = c2 = c3 = -1;
-        l0 = l1 = l2 = l3 = 0.0f;
         best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
         best_obj = -1; best_tri = false;
     }
@@ -450,8 +454,8 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
             }
             if (leaf_hits) {                                        // only reached with no candidates pending
                 ts.leaf_mask = leaf_hits;
-                ts.c0 = codes[0]; ts.c1 = codes[1]; ts.c2 = codes[2]; ts.c3 = codes[3];
-                ts.l0 = los[0]; ts.l1 = los[1]; ts.l2 = los[2]; ts.l3 = los[3];
+                stk.code[0] = codes[0]; stk.code[stk.stride] = codes[1]; stk.code[2 * stk.stride] = codes[2]; stk.code[3 * stk.stride] = codes[3];
+                stk.entry[0] = los[0]; stk.entry[stk.stride] = los[1]; stk.entry[2 * stk.stride] = los[2]; stk.entry[3 * stk.stride] = los[3];
             }
             ts.node = ts.sp ? stk.get(--ts.sp) : -1;
         }
@@ -462,8 +466,8 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
             if (has_prim) {
                 const int i = __builtin_ctz(ts.leaf_mask);
                 ts.leaf_mask &= ts.leaf_mask - 1;
-                const int code = i == 0 ? ts.c0 : (i == 1 ? ts.c1 : (i == 2 ? ts.c2 : ts.c3));
-                const float lo = i == 0 ? ts.l0 : (i == 1 ? ts.l1 : (i == 2 ? ts.l2 : ts.l3));
+                const int code = stk.code[i * stk.stride];
+                const float lo = stk.entry[i * stk.stride];
                 // an earlier candidate may have shrunk the interval below this box's entry
                 if (!(ts.best.t < lo)) {
                     CRT_PROF(kProfPrim);

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
     // parks them in lanes of a vector register and fetches each one back with a v_readlane.
     DevCamera* lds_cam = reinterpret_cast<DevCamera*>(coop_all + kWaves * kCoopWordsPerWave);
     int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords);
-    float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
+    float* entry_mem = reinterpret_cast<float*>(stack_mem + STACK * kBlock);      // tree modes: 4 slot codes + 4 box entry distances per lane
+    float4* lds_scene = reinterpret_cast<float4*>(entry_mem + (MODE == kModeFlat ? 0 : 8 * kBlock));
     const DevScene& sc = A.sc;
     if (threadIdx.x == 0) *lds_cam = sc.cam;
 
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
     stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
     stk.stride = kBlock;
     stk.lds_entries = STACK;
+    stk.entry = (LdsFloatPtr)(entry_mem + threadIdx.x);
+    stk.code = (LdsIntPtr)(reinterpret_cast<int*>(entry_mem) + 4 * kBlock + threadIdx.x);
     stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
     stk.spill_stride = (size_t)A.spill_threads;
 
@@ -415,6 +418,364 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
     }
 }
 
+// ===================================================================== wavefront path ====
+// The path loop cut into kernels per bounce with the path state in HBM (crt_scene_options.wavefront):
+//   wf_generate    camera rays of a batch of samples -> queue of bounce 0
+//   wf_trace       closest hits of the rays of the current queue.  Persistent waves; a lane whose
+//                  walk has ended writes its hit and takes the NEXT RAY of the queue at once
+//                  (in the fused kernel it waits until enough other lanes have finished, because
+//                  its next ray only exists after shading); carrying walk state only, the kernel
+//                  needs 75 registers and fits six waves per SIMD
+//   wf_shade       surface, scatter / emit / environment for every hit of the queue (every lane
+//                  busy); surviving paths move to the next queue; results go to per-path records
+//                  keyed by (sample, pixel)
+//   wf_accumulate  adds the batch's per-path records, in sample order, to the pixel sums that
+//                  resolve_passes turns into the pass buffers.
+// A queue is cut into SEGMENTS of kWfSegment slots.  Segment k of bounce b+1 receives the survivors
+// of segment k of bounce b, packed at its front, and a count per segment says how many there are:
+// compaction needs no global atomic at all (one workgroup owns a segment and counts in LDS; a
+// single device-wide queue tail would take one same-address atomic per wave, which serialises at
+// 12-50 ns each - 12 ms for the first bounce of a 4K frame), and every access of trace and shade
+// is a dense float4 per lane (the state moves with the path from queue to queue).  Same device
+// functions, same bits as the fused kernel; sums are added in sample order, so a bulk render is
+// reproducible bit for bit.
+//
+// Measured (MI355X): the walk's loops do run fuller (1 M triangles: node steps at 79 % of the lanes
+// against 43 % in the fused kernel, 18 instead of 34 wave-level node steps per 64 rays), but the
+// frame is not faster: 44.6 ms against 37.2 ms for the million-triangle scene at 8 spp (trace
+// 34.7, shade 8.1, generate + accumulate 1.8), 26 ms against 12.4 ms for the 976-triangle mesh
+// scene.  Both pipelines fetch the same 28-30 GB per frame into L2 (about 210 bytes per ray: nodes
+// and triangles, 190 MB, do not stay in the 4 MB of an XCD's L2), and with a tenth of all node and
+// triangle reads missing L2 nearly every wave-level step waits for one of its lanes' misses; four
+// or six waves per SIMD made no difference to the trace kernel.  The fused kernel stays the
+// default for every scene; this pipeline is kept for what it adds: bulk renders that are
+// reproducible bit for bit with per-path records instead of per-sample chunk sums.
+struct WfQueue {
+    float4 *ray0, *ray1;     // (o.xyz, d.x)  (d.y, d.z, time, -)
+    float4 *st0, *st1;       // (throughput.xyz, rng.state)  (pending albedo.xyz, rng.draws)
+    uint2* meta;             // (path id within the batch, bounces so far)
+    unsigned int* count;     // [segments] live slots at the front of each segment
+};
+struct WfArgs {
+    DevScene sc;
+    WfQueue cur, next;
+    float4* hit;                     // [slot of cur] (t, object, bu, bv)
+    float4* res;                     // [4][batch_capacity] by path id: (color|depth) (albedo|opacity) (emission|0) (normal|0)
+    unsigned int* cursors;           // [max_bounces + 1][kWfCursors] (padded) next entry of each segment list of a bounce
+    unsigned long long* ray_counter;
+    unsigned long long* block_rays;  // [trace grid] rays taken per workgroup of wf_trace, summed by wf_sum_rays
+    float* partial;                  // [14][pix_padded] pixel sums of the launch
+    int bounce;
+    int segments;                    // segments of this batch's queues
+    int batch_samples, batch_capacity;   // samples in this batch; stride of the res planes
+    int first_sample;                // sample number of the batch's first sample is first_sample + 1
+    int pix_padded, tiles_x, band_tiles, band_index, band_count;
+    int* stack_spill;
+    int spill_threads;
+    int prim_batch;
+    int refill_lanes;                // wf_trace: hand out new rays once this many lanes of a wave are idle
+    int accumulate_first;            // wf_accumulate: 1 = overwrite the sums (first batch of a launch)
+};
+
+constexpr int kWfTileH = 4;          // 8x4-pixel tiles like the tree modes of the fused kernel
+constexpr int kWfTilePixels = kTileW * kWfTileH;
+constexpr int kWfSegment = 1024;     // slots per queue segment (a multiple of the workgroup size)
+// Trace waves take segments in ascending order, so that at any moment the whole chip works on one
+// narrow band of the image (path ids run tile by tile with all samples of a tile together) and the
+// part of the hierarchy in use stays in L2.  One cursor for all waves would be one same-address
+// atomic per segment, about 50 ns each; instead the segments are dealt round-robin to
+// kWfCursors lists with a cursor each (one cache line apart), a wave starts on the list of its own
+// number and moves on to the next list when one runs out.
+constexpr int kWfCursors = 64;
+constexpr int kWfCursorStride = 32;  // unsigned ints between cursors: 128 bytes
+#ifndef CRT_WF_TRACE_WAVES_PER_SIMD
+#define CRT_WF_TRACE_WAVES_PER_SIMD 6
+#endif
+
+// Position in the segment's output for the lanes of this wave that keep a path (`keep`): the
+// workgroup's running count lives in LDS.
+__device__ __forceinline__ unsigned int wf_segment_slot(bool keep, unsigned int* lds_count, int lane) {
+    const unsigned long long mask = __ballot(keep);
+    unsigned int off = 0;
+    if (lane == 0 && mask) off = atomicAdd(lds_count, (unsigned int)__builtin_popcountll(mask));
+    return __builtin_amdgcn_readfirstlane(off) + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(kBlock) void wf_generate(WfArgs A) {
+    __shared__ unsigned int out_count;
+    const DevScene& sc = A.sc;
+    const int lane = threadIdx.x & 63;
+    const long long total = (long long)A.batch_samples * A.pix_padded;
+    for (int seg = blockIdx.x; seg < A.segments; seg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) out_count = 0;
+        __syncthreads();
+        const size_t base = (size_t)seg * kWfSegment;
+        for (int i = threadIdx.x; i < kWfSegment; i += kBlock) {
+            const long long p = (long long)base + i;
+            bool live = false;
+            Ray ray;
+            ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
+            Rng rng;
+            rng.state = 0; rng.draws = 0;
+            if (p < total && sc.max_bounces > 0) {
+                // path id = (tile * samples + sample) * 32 + pixel of the tile
+                const int pix = (int)(p % kWfTilePixels);
+                const long long ts = p / kWfTilePixels;
+                const int s = (int)(ts % A.batch_samples), tile = (int)(ts / A.batch_samples);
+                const int pi = (tile % A.tiles_x) * kTileW + (pix & 7);
+                const int pj = band_global_tile_row(tile / A.tiles_x, A.band_tiles, A.band_index, A.band_count) * kWfTileH + (pix >> 3);
+                if (pi < sc.width && pj < sc.height) {
+                    rng.init(pj * sc.width + pi, A.first_sample + s + 1);      // sample numbers are 1-based (render.cuh:128)
+                    ray = camera_ray(sc.cam, pi, pj, rng);
+                    live = true;
+                }
+            }
+            const size_t slot = base + wf_segment_slot(live, &out_count, lane);
+            if (live) {
+                A.cur.ray0[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+                A.cur.ray1[slot] = make_float4(ray.d.y, ray.d.z, ray.time, 0.0f);
+                A.cur.st0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.state));
+                A.cur.st1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.draws));
+                A.cur.meta[slot] = make_uint2((unsigned int)p, 0u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) A.cur.count[seg] = out_count;
+    }
+}
+
+template <int STACK, int FAST>
+__global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(WfArgs A) {
+    extern __shared__ float4 smem[];
+    int* stack_mem = reinterpret_cast<int*>(smem);
+    const DevScene& sc = A.sc;
+    const int lane = threadIdx.x & 63;
+    SceneGlobal S;
+    S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+    LaneStack stk;
+    stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
+    stk.stride = kBlock;
+    stk.lds_entries = STACK;
+    stk.entry = (LdsFloatPtr)(reinterpret_cast<float*>(stack_mem + STACK * kBlock) + threadIdx.x);
+    stk.code = (LdsIntPtr)(stack_mem + (STACK + 4) * kBlock + threadIdx.x);
+    stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
+    stk.spill_stride = (size_t)A.spill_threads;
+
+    // A wave takes one segment of the queue at a time (one atomic per segment) and hands its rays
+    // to the lanes as their walks end.
+    size_t have_lo = 0, have_hi = 0;                 // wave-uniform: slots [have_lo, have_hi) still to hand out
+    bool dry = false;                                // no segment left
+    int list = (int)((blockIdx.x * kWaves + (threadIdx.x >> 6)) % kWfCursors);   // wave-uniform: the segment list in use
+    unsigned int* const cursors = A.cursors + (size_t)A.bounce * kWfCursors * kWfCursorStride;
+    unsigned long long rays = 0;                     // wave-uniform: rays this wave took
+    Ray ray;
+    ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
+    TreeState ts;
+    ts.begin(INFINITY, sc.root_entry);
+    bool walking = false;
+    size_t slot = 0;
+    while (true) {
+        // hand rays to the lanes without one
+        while (!dry) {
+            const unsigned long long idle = __ballot(!walking);
+            if (!idle) break;
+            if (have_lo == have_hi) {
+                unsigned int k = 0;
+                if (lane == 0) k = atomicAdd(&cursors[list * kWfCursorStride], 1u);
+                k = __builtin_amdgcn_readfirstlane(k) * kWfCursors + (unsigned int)list;
+                if (k >= (unsigned int)A.segments) {
+                    // this list has run out: look at all cursors at once (lane l reads list l's) and
+                    // move to the next list that still has segments, if any
+                    const unsigned int seen = __hip_atomic_load(&cursors[lane * kWfCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long open = __ballot((unsigned long long)seen * kWfCursors + (unsigned int)lane < (unsigned long long)A.segments);
+                    if (!open) { dry = true; break; }
+                    const unsigned long long after = open & ~((2ull << list) - 1ull);
+                    list = after ? __builtin_ctzll(after) : __builtin_ctzll(open);
+                    continue;
+                }
+                const unsigned int n = A.cur.count[k];
+                have_lo = (size_t)k * kWfSegment;
+                have_hi = have_lo + n;
+                rays += n;
+                continue;
+            }
+            const unsigned int rank = (unsigned int)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            const unsigned int take = (unsigned int)min((size_t)__builtin_popcountll(idle), have_hi - have_lo);
+            if (!walking && rank < take) {
+                slot = have_lo + rank;
+                const float4 r0 = A.cur.ray0[slot], r1 = A.cur.ray1[slot];
+                ray.o = v3(r0.x, r0.y, r0.z); ray.d = v3(r0.w, r1.x, r1.y); ray.time = r1.z;
+                ts.begin(INFINITY, sc.root_entry);
+                walking = true;
+            }
+            have_lo += take;
+        }
+        const int active = __builtin_popcountll(__ballot(walking));
+        if (active == 0) break;
+        // walk until 8 lanes have finished (or, with the queue dry, until every walk has ended)
+        const bool was = walking;
+        tree_run<FAST>(S, ray, 0.001f, ts, walking, stk, dry ? 1 : max(1, active - A.refill_lanes + 1), A.prim_batch);
+        if (was && !walking) {
+            const Hit h = ts.result();
+            A.hit[slot] = make_float4(h.t, __int_as_float(h.obj), h.bu, h.bv);
+        }
+    }
+    // a ray = one closest-hit query.  Counted per workgroup in a slot of its own (thousands of
+    // atomics on one address would cost more than a late bounce's whole walk)
+    __shared__ unsigned long long block_sum;
+    if (threadIdx.x == 0) block_sum = 0;
+    __syncthreads();
+    if (lane == 0 && rays) atomicAdd(&block_sum, rays);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_sum) A.block_rays[blockIdx.x] += block_sum;
+}
+
+// Adds up the per-workgroup ray counts of the trace kernels of a launch and clears them.
+__global__ __launch_bounds__(kBlock) void wf_sum_rays(unsigned long long* block_rays, int blocks, unsigned long long* ray_counter) {
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int b = threadIdx.x; b < blocks; b += kBlock) { mine += block_rays[b]; block_rays[b] = 0; }
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *ray_counter += total;
+}
+
+__global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
+    __shared__ uint32_t coop_all[kWaves * kCoopWordsPerWave];
+    __shared__ unsigned int out_count;
+    const DevScene& sc = A.sc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
+    float* coop_res = reinterpret_cast<float*>(coop_pub + 128);
+    const size_t cap = (size_t)A.batch_capacity;
+    for (int seg = blockIdx.x; seg < A.segments; seg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) out_count = 0;
+        __syncthreads();
+        const unsigned int count = A.cur.count[seg];
+        const size_t seg_base = (size_t)seg * kWfSegment;
+        for (unsigned int first = 0; first < count; first += kBlock) {
+        const unsigned int i = first + threadIdx.x;
+        const bool active = i < count;
+        const size_t in = seg_base + i;
+        Ray ray;
+        ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
+        V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
+        Rng rng;
+        rng.state = 0; rng.draws = 0;
+        unsigned int path = 0, bounces = 0;
+        Hit h;
+        h.t = 0.0f; h.obj = -1; h.bu = 0.0f; h.bv = 0.0f;
+        if (active) {
+            const float4 r0 = A.cur.ray0[in], r1 = A.cur.ray1[in], s0 = A.cur.st0[in], s1 = A.cur.st1[in], hh = A.hit[in];
+            const uint2 m = A.cur.meta[in];
+            ray.o = v3(r0.x, r0.y, r0.z); ray.d = v3(r0.w, r1.x, r1.y); ray.time = r1.z;
+            throughput = v3(s0.x, s0.y, s0.z); rng.state = __float_as_uint(s0.w);
+            pend_albedo = v3(s1.x, s1.y, s1.z); rng.draws = __float_as_uint(s1.w);
+            path = m.x; bounces = m.y;
+            h.t = hh.x; h.obj = __float_as_int(hh.y); h.bu = hh.z; h.bv = hh.w;
+        }
+        Surface sf = {};
+        float4 m0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int mat_type = -1;
+        if (active && h.obj >= 0) {
+            sf = make_surface<false>(sc, ray, h);
+            m0 = sc.mats[sf.mat * 2];
+            mat_type = __float_as_int(m0.x);
+        }
+        const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
+        bool alive = false;                                   // the path goes on to the next bounce
+        if (active) {
+            // what this segment of the path contributes; the aov values exist at bounce 0 only (render.cuh:53-58,67-73,84-90)
+            V3 color = v3(0, 0, 0), albedo = v3(0, 0, 0), emission = v3(0, 0, 0), normal = v3(0, 0, 0);
+            float depth = 0.0f, opacity = 0.0f;
+            bool ended = false;
+            if (h.obj >= 0) {
+                V3 attenuation;
+                Ray next;
+                if (scatter_with(sc, ray, sf, m0, rv, rng, attenuation, next)) {             // render.cuh:52-61
+                    if (bounces == 0) {
+                        pend_albedo = attenuation;
+                        normal = sf.has_unit ? sf.unit_normal : unit(sf.normal);
+                        depth = h.t * length(ray.d);
+                        opacity = 1.0f;
+                    }
+                    throughput = throughput * attenuation;
+                    ray = next;
+                    alive = bounces + 1 < (unsigned int)sc.max_bounces;     // exhausted: col = albedo = 0 (render.cuh:96-97)
+                } else {                                                                      // render.cuh:64-74
+                    const V3 emitted = emit(sc, sf);
+                    color = throughput * emitted;
+                    albedo = pend_albedo;
+                    if (bounces == 0) {
+                        albedo = emitted;
+                        emission = emitted;
+                        normal = sf.has_unit ? sf.unit_normal : unit(sf.normal);
+                        depth = h.t * length(ray.d);
+                        opacity = 1.0f;
+                    }
+                    ended = true;
+                }
+            } else {                                                                          // render.cuh:76-91
+                color = throughput * environment(sc, ray.d);
+                albedo = pend_albedo;
+                if (bounces == 0) {
+                    albedo = color;
+                    depth = __builtin_nanf("");                // depth of a miss is NaN (render.cuh:88)
+                }
+                ended = true;
+            }
+            float4* R = A.res + path;
+            if (bounces == 0) {                                // the record is written whole at bounce 0
+                R[0] = make_float4(color.x, color.y, color.z, depth);
+                R[cap] = make_float4(albedo.x, albedo.y, albedo.z, opacity);
+                R[2 * cap] = make_float4(emission.x, emission.y, emission.z, 0.0f);
+                R[3 * cap] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+            } else if (ended) {                                // later: colour and albedo of the path's end
+                float* r0 = reinterpret_cast<float*>(R);
+                float* r1 = reinterpret_cast<float*>(R + cap);
+                r0[0] = color.x; r0[1] = color.y; r0[2] = color.z;
+                r1[0] = albedo.x; r1[1] = albedo.y; r1[2] = albedo.z;
+            }
+        }
+        const size_t out = seg_base + wf_segment_slot(alive, &out_count, lane);
+        if (alive) {
+            A.next.ray0[out] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+            A.next.ray1[out] = make_float4(ray.d.y, ray.d.z, ray.time, 0.0f);
+            A.next.st0[out] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.state));
+            A.next.st1[out] = make_float4(pend_albedo.x, pend_albedo.y, pend_albedo.z, __uint_as_float(rng.draws));
+            A.next.meta[out] = make_uint2(path, bounces + 1u);
+        }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) A.next.count[seg] = out_count;
+    }
+}
+
+// Adds the per-path records of a batch to the pixel sums, samples in ascending order.
+__global__ __launch_bounds__(kBlock) void wf_accumulate(WfArgs A) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= A.pix_padded) return;
+    const size_t cap = (size_t)A.batch_capacity;
+    float v[kPasses];
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) v[k] = A.accumulate_first ? 0.0f : A.partial[(size_t)k * A.pix_padded + t];
+    const int tile = t / kWfTilePixels, pix = t - tile * kWfTilePixels;
+    for (int s = 0; s < A.batch_samples; s++) {
+        const float4* R = A.res + ((size_t)tile * A.batch_samples + s) * kWfTilePixels + pix;
+        const float4 a = R[0], b = R[cap], c = R[2 * cap], d = R[3 * cap];
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[12] += a.w;
+        v[3] += b.x; v[4] += b.y; v[5] += b.z; v[13] += b.w;
+        v[6] += c.x; v[7] += c.y; v[8] += c.z;
+        v[9] += d.x; v[10] += d.y; v[11] += d.z;
+    }
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) A.partial[(size_t)k * A.pix_padded + t] = v[k];
+}
+
 // Multi-GPU tile split: builds the full pass arrays from the ranks' band buffers after an
 // all-gather.  gathered + r * stride holds rank r's six arrays back to back (color, albedo,
 // emission, normal as [rows_r * W][3], depth and opacity as [rows_r * W]) for the rows it owns.
@@ -462,7 +823,7 @@ template <int MODE, int STACK, int GROUPS>
 __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
     extern __shared__ float4 smem[];
     int* stack_mem = reinterpret_cast<int*>(smem);
-    float4* lds_scene = reinterpret_cast<float4*>(stack_mem + STACK * kBlock);
+    float4* lds_scene = reinterpret_cast<float4*>(stack_mem + (STACK + (MODE == kModeFlat ? 0 : 8)) * kBlock);
     const DevScene& sc = A.sc;
     FlatLds FL = {};
     if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
@@ -486,6 +847,8 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
             stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
             stk.stride = kBlock;
             stk.lds_entries = STACK;
+            stk.entry = (LdsFloatPtr)(reinterpret_cast<float*>(stack_mem + STACK * kBlock) + threadIdx.x);
+            stk.code = (LdsIntPtr)(stack_mem + (STACK + 4) * kBlock + threadIdx.x);
             stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
             stk.spill_stride = (size_t)A.spill_threads;
             h = traverse(S, ray, 0.001f, INFINITY, stk);
@@ -595,6 +958,7 @@ constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
+constexpr int kWfMaxTraceBlocks = 8192;
 static unsigned char* g_static_scratch[kMaxDevices];     // device address of `scratch` on each GPU
 static std::mutex g_static_scratch_mutex;
 
@@ -621,7 +985,7 @@ struct crt_scene {
     std::vector<void*> image_mem;
     DevScene dev = {};
     crt_render_info render = {};
-    int stack_entries = 8;           // LDS entries of the traversal stack (8 or 16)
+    int stack_entries = 8;           // LDS entries of the traversal stack (8 or 12)
     int spill_entries = 0;           // entries beyond them, in global memory
     int spill_threads = 0;
     int* stack_spill = nullptr;
@@ -638,6 +1002,15 @@ struct crt_scene {
     unsigned char* static_scratch = nullptr;     // this GPU's copy of `scratch` (crt_render_static)
     crt_scene_options opt = {};
     bool launched = false;
+    // wavefront path (large scenes): queues, hits and per-path records for one batch of samples
+    bool wavefront = false;
+    size_t wf_capacity = 0;          // paths per batch
+    void* wf_mem = nullptr;          // everything below, one allocation
+    WfQueue wf_queue[2] = {};
+    float4* wf_hit = nullptr;
+    float4* wf_res = nullptr;
+    unsigned int* wf_cursors = nullptr;  // [max_bounces + 1] segment cursors of the trace kernels
+    unsigned long long* wf_block_rays = nullptr;   // [kWfMaxTraceBlocks], zero between launches
 };
 
 struct crt_buffers {
@@ -751,6 +1124,7 @@ void free_scene(crt_scene* sc) {
     for (void* p : sc->image_mem) (void)hipFree(p);
     if (sc->blob) (void)hipFree(sc->blob);
     if (sc->partial) (void)hipFree(sc->partial);
+    if (sc->wf_mem) (void)hipFree(sc->wf_mem);
     if (sc->ray_counter) (void)hipFree(sc->ray_counter);
     if (sc->host_counter) (void)hipHostFree(sc->host_counter);
     if (sc->stack_spill) (void)hipFree(sc->stack_spill);
@@ -772,7 +1146,7 @@ int kernel_mode(const crt_scene* sc) {
 
 template <int STACK, int FAST>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
-    size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)STACK * kBlock * sizeof(int);
+    size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)(STACK + 8) * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
         hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0, FAST>), grid, dim3(kBlock), lds, sc->stream, A);
@@ -801,8 +1175,8 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
         CRT_HIP(hipGetLastError());
         return CRT_OK;
     }
-    if (sc->dev.fast_rcp) return sc->stack_entries == 8 ? launch_tree<8, 1>(sc, A, grid, mode) : launch_tree<16, 1>(sc, A, grid, mode);
-    return sc->stack_entries == 8 ? launch_tree<8, 0>(sc, A, grid, mode) : launch_tree<16, 0>(sc, A, grid, mode);
+    if (sc->dev.fast_rcp) return sc->stack_entries == 8 ? launch_tree<8, 1>(sc, A, grid, mode) : launch_tree<12, 1>(sc, A, grid, mode);
+    return sc->stack_entries == 8 ? launch_tree<8, 0>(sc, A, grid, mode) : launch_tree<12, 0>(sc, A, grid, mode);
 }
 
 // True when every divisor the kernels invert on the path (triangle determinants that pass the
@@ -980,6 +1354,63 @@ ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacit
     return p;
 }
 
+template <int STACK>
+void launch_wf_trace(crt_scene* sc, const WfArgs& W, dim3 grid) {
+    const size_t lds = (size_t)(STACK + 8) * kBlock * sizeof(int);
+    if (sc->dev.fast_rcp) hipLaunchKernelGGL((wf_trace<STACK, 1>), grid, dim3(kBlock), lds, sc->stream, W);
+    else hipLaunchKernelGGL((wf_trace<STACK, 0>), grid, dim3(kBlock), lds, sc->stream, W);
+}
+
+// The wavefront pipeline for one launch: the samples in batches that fit the path buffers, per
+// batch one generate, max_bounces x (trace, shade) and one accumulate, all on the scene's stream
+// with the queue lengths kept on the device (no host round trip between bounces).
+int launch_wavefront(crt_scene* sc, const RenderArgs& A, const ChunkPlan& plan, Bands bands) {
+    WfArgs W;
+    W.sc = sc->dev;
+    W.hit = sc->wf_hit;
+    W.res = sc->wf_res;
+    W.cursors = sc->wf_cursors;
+    W.ray_counter = A.ray_counter;
+    W.block_rays = sc->wf_block_rays;
+    W.partial = A.partial;
+    W.batch_capacity = (int)std::min<size_t>(sc->wf_capacity, 0x7fffffff);
+    W.pix_padded = plan.pix_padded; W.tiles_x = plan.tiles_x;
+    W.band_tiles = plan.band_tiles; W.band_index = bands.index; W.band_count = bands.count;
+    W.stack_spill = sc->stack_spill; W.spill_threads = sc->spill_threads;
+    W.prim_batch = A.prim_batch;
+    W.refill_lanes = sc->opt.ready_percent > 0 ? std::max(1, 64 * sc->opt.ready_percent / 100) : 8;
+    const int per_batch = (int)std::max<size_t>(1, sc->wf_capacity / (size_t)plan.pix_padded);
+    if ((size_t)plan.pix_padded > sc->wf_capacity) return crt::set_error(CRT_ERR_UNSUPPORTED, "wavefront buffers hold less than one sample of this image");
+    const int resident = sc->cu_count * 4;                                  // generate / shade / accumulate: grid-stride
+    const dim3 trace_grid((unsigned)std::min(std::min(sc->cu_count * CRT_WF_TRACE_WAVES_PER_SIMD, sc->spill_threads / kBlock), kWfMaxTraceBlocks));
+    const size_t counter_bytes = (size_t)(sc->dev.max_bounces + 1) * kWfCursors * kWfCursorStride * sizeof(unsigned int);
+    for (int done = 0; done < A.samples; done += per_batch) {
+        W.batch_samples = std::min(per_batch, A.samples - done);
+        W.first_sample = A.first_sample + done;
+        W.accumulate_first = done == 0 ? 1 : 0;
+        const long long paths = (long long)W.batch_samples * plan.pix_padded;
+        W.segments = (int)((paths + kWfSegment - 1) / kWfSegment);
+        CRT_HIP(hipMemsetAsync(sc->wf_cursors, 0, counter_bytes, sc->stream));
+        if (sc->dev.max_bounces == 0) CRT_HIP(hipMemsetAsync(sc->wf_res, 0, sc->wf_capacity * 64, sc->stream));   // no path starts: all records zero
+        W.cur = sc->wf_queue[0]; W.next = sc->wf_queue[1];
+        W.bounce = 0;
+        const dim3 wide((unsigned)std::min<long long>(W.segments, (long long)resident * 2));
+        hipLaunchKernelGGL(wf_generate, wide, dim3(kBlock), 0, sc->stream, W);
+        for (int b = 0; b < sc->dev.max_bounces; b++) {
+            W.bounce = b;
+            if (sc->stack_entries == 8) launch_wf_trace<8>(sc, W, trace_grid);
+            else launch_wf_trace<12>(sc, W, trace_grid);
+            hipLaunchKernelGGL(wf_shade, wide, dim3(kBlock), 0, sc->stream, W);
+            std::swap(W.cur, W.next);
+        }
+        hipLaunchKernelGGL(wf_accumulate, dim3((unsigned)((plan.pix_padded + kBlock - 1) / kBlock)), dim3(kBlock), 0, sc->stream, W);
+        CRT_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(wf_sum_rays, dim3(1), dim3(kBlock), 0, sc->stream, sc->wf_block_rays, (int)trace_grid.x, A.ray_counter);
+    CRT_HIP(hipGetLastError());
+    return CRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1033,6 +1464,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     opt.struct_size = (int32_t)sizeof(opt);
     if (opt.accel < CRT_ACCEL_AUTO || opt.accel > CRT_ACCEL_ORDERED) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->accel must be CRT_ACCEL_*");
     if (opt.mode < 0 || opt.mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->mode must be 0..3");
+    if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
         return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
     int bvh_depth = 0;
@@ -1056,7 +1488,9 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         need = 3 * (accel_depth - 1) + 1;
     }
     if (need > 1024) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: hierarchy deeper than 342 levels");
-    const int stack_entries = need <= 8 ? 8 : 16;
+    // LDS part of the traversal stack: 8 entries for shallow trees, else 12 (deeper entries go to the
+    // global part; with the 8 words of pending candidates beside it a workgroup stays under 40 KB)
+    const int stack_entries = need <= 8 ? 8 : 12;
 
     const int nodes = (int)accel.size();
     auto accel_leafy = [&](int node) {
@@ -1309,7 +1743,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
     sc->spill_entries = std::max(0, need - stack_entries);
-    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(CRT_FUSED_WAVES_PER_SIMD, CRT_TREE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
+    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(CRT_FUSED_WAVES_PER_SIMD, CRT_TREE_WAVES_PER_SIMD), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
         CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
     }
@@ -1350,7 +1784,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     sc->stack_entries = stack_entries;
     sc->lds_scene_bytes = (int)(((size_t)nodes * kNodeFields + (size_t)d->object_count * kPrimQuads) * 16 + xforms.size() * 4);
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
-    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)stack_entries * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
+    sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)(stack_entries + 8) * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
     sc->can_flat = can_flat;
     sc->ordered = ordered;
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
@@ -1376,6 +1810,43 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: scratch allocation: ") + hipGetErrorString(e));
         *sc->host_counter = 0;
     }
+    // Wavefront pipeline: on request only (measured slower than the fused kernel on every scene of
+    // this repository, see the kernel comments).  One batch holds as many whole samples of the
+    // image as fit `wavefront_paths` path slots of 224 bytes.
+    {
+        sc->wavefront = opt.wavefront == 1;
+        if (sc->wavefront) {
+            const ChunkPlan tiles = plan_chunks(sc, kModeTreeGlobal, 1, (size_t)-1);
+            const size_t budget = opt.wavefront_paths > 0 ? (size_t)opt.wavefront_paths : (size_t)64 << 20;
+            const size_t samples = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, d->render.samples_per_pixel), budget / (size_t)tiles.pix_padded));
+            const size_t cap = samples * (size_t)tiles.pix_padded;
+            const size_t segments = (cap + kWfSegment - 1) / kWfSegment;
+            const size_t counters = (size_t)(d->render.max_bounces + 1) * kWfCursors * kWfCursorStride * sizeof(unsigned int);
+            const size_t seg_counts = (segments * sizeof(unsigned int) + 255) & ~(size_t)255;
+            const size_t slots = segments * kWfSegment;            // queues are whole segments
+            const size_t block_rays = (size_t)kWfMaxTraceBlocks * sizeof(unsigned long long);
+            const size_t bytes = slots * (2 * (4 * 16 + 8) + 16) + cap * 4 * 16 + counters + 2 * seg_counts + block_rays;
+            hipError_t e = hipMalloc(&sc->wf_mem, bytes);
+            if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: wavefront buffers (") + std::to_string(bytes >> 20) + " MiB): " + hipGetErrorString(e));
+            unsigned char* m = static_cast<unsigned char*>(sc->wf_mem);
+            auto take = [&](size_t n) { unsigned char* r = m; m += n; return r; };
+            sc->wf_cursors = reinterpret_cast<unsigned int*>(take(counters));
+            sc->wf_block_rays = reinterpret_cast<unsigned long long*>(take(block_rays));
+            e = hipMemset(sc->wf_block_rays, 0, block_rays);
+            if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: ") + hipGetErrorString(e));
+            for (int q = 0; q < 2; q++) {
+                sc->wf_queue[q].count = reinterpret_cast<unsigned int*>(take(seg_counts));
+                sc->wf_queue[q].ray0 = reinterpret_cast<float4*>(take(slots * 16));
+                sc->wf_queue[q].ray1 = reinterpret_cast<float4*>(take(slots * 16));
+                sc->wf_queue[q].st0 = reinterpret_cast<float4*>(take(slots * 16));
+                sc->wf_queue[q].st1 = reinterpret_cast<float4*>(take(slots * 16));
+            }
+            sc->wf_hit = reinterpret_cast<float4*>(take(slots * 16));
+            sc->wf_res = reinterpret_cast<float4*>(take(cap * 64));
+            for (int q = 0; q < 2; q++) sc->wf_queue[q].meta = reinterpret_cast<uint2*>(take(slots * 8));
+            sc->wf_capacity = cap;
+        }
+    }
     guard.sc = nullptr;
     *out = sc;
     return CRT_OK;
@@ -1396,9 +1867,10 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s", names[kernel_mode(sc)],
+    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)],
                                 sc->flat.slot_count, sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
-                                sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free");
+                                sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
+                                sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");
     if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);
     return n;
 }
@@ -1514,7 +1986,8 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     if (sc->opt.blocks > 0) resident = std::min(sc->spill_threads / kBlock, sc->opt.blocks);
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
-    int rc = launch_fused(sc, A, grid);
+    const bool wavefront = sc->wavefront && kernel_mode(sc) == kModeTreeGlobal;
+    int rc = wavefront ? launch_wavefront(sc, A, plan, bands) : launch_fused(sc, A, grid);
     if (rc != CRT_OK) return rc;
     CRT_HIP(hipEventRecord(sc->ev_mid, sc->stream));
     ResolveArgs R;
@@ -1522,7 +1995,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
     R.depth = buf->depth(); R.opacity = buf->opacity();
     R.width = sc->dev.width; R.height = sc->dev.height; R.tiles_x = plan.tiles_x; R.tile_rows = plan.tile_h; R.ntiles = plan.ntiles; R.pix_padded = plan.pix_padded;
-    R.chunks = plan.chunks;
+    R.chunks = wavefront ? 1 : plan.chunks;
     R.done = (float)fold_done;
     R.count = (float)samples;
     R.fold = fold_done > 0 ? 1 : 0;
@@ -1739,8 +2212,8 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
         default: hipLaunchKernelGGL((trace_primary_kernel<kModeFlat, 0, 2>), grid, dim3(kBlock), lds, sc->stream, A); break;
         }
     } else {
-        if (sc->stack_entries == 8) hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), 8 * kBlock * 4, sc->stream, A);
-        else hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 16, 0>), grid, dim3(kBlock), 16 * kBlock * 4, sc->stream, A);
+        if (sc->stack_entries == 8) hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), (8 + 8) * kBlock * 4, sc->stream, A);
+        else hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 12, 0>), grid, dim3(kBlock), (12 + 8) * kBlock * 4, sc->stream, A);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);

@@ -196,6 +196,10 @@ typedef struct crt_scene_options {
                                  a render is bit-reproducible from run to run (costs 56 B of scratch per
                                  pixel AND sample instead of per pixel and chunk; a call may then render
                                  at most samples_per_pixel samples)                              */
+    int32_t wavefront;        /* BVH walk in HBM: 1 = wavefront pipeline (path state in HBM, one trace and one shade
+                                 kernel per bounce, per-path result records: bulk renders reproducible bit for bit;
+                                 measured slower than the fused kernel), 0 or 2 = the fused kernel (default) */
+    int32_t wavefront_paths;  /* path slots (224 bytes each) of the wavefront buffers; 0 = 67 108 864   */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 

@@ -376,7 +376,7 @@ def test_kernel_variant_selection(crt):
     d = describe("nested_wrappers.yaml")
     assert d["mode"] in ("tree_lds", "tree_hbm") and d["order"] == "reference"
     d = describe("obj.yaml", width=64, height=64)
-    assert d["mode"] == "tree_hbm" and d["stack"].startswith("16+") and d["objects"] == "976"
+    assert d["mode"] == "tree_hbm" and d["stack"].startswith("12+") and d["objects"] == "976"
     # a fuzz beyond the range the bound proof covers falls back to IEEE division
     sc = crt.parse_scene(TIES.replace("type: metal, color: [0.9, 0.9, 0.9]", "type: metal, color: [0.9, 0.9, 0.9], fuzz: 1.0e35"))
     assert "reciprocal=ieee" in sc.describe()

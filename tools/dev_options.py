@@ -15,7 +15,8 @@ def from_env(env=os.environ):
     if env.get("CRT_FAST_RCP") == "0":
         opt["ieee_division"] = 1
     for var, name in (("CRT_TARGET_WAVES", "work_items"), ("CRT_BLOCKS", "blocks"), ("CRT_READY_PERCENT", "ready_percent"),
-                      ("CRT_PRIM_BATCH", "prim_batch"), ("CRT_DETERMINISTIC", "deterministic")):
+                      ("CRT_PRIM_BATCH", "prim_batch"), ("CRT_DETERMINISTIC", "deterministic"), ("CRT_WAVEFRONT", "wavefront"),
+                      ("CRT_WAVEFRONT_PATHS", "wavefront_paths")):
         if var in env:
             opt[name] = int(env[var])
     return opt

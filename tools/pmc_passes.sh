@@ -22,7 +22,7 @@ import csv, glob, collections
 tot = collections.defaultdict(float)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "render_fused" in row["Kernel_Name"] or "trace_" in row["Kernel_Name"] or "shade" in row["Kernel_Name"]:
+        if any(k in row["Kernel_Name"] for k in ("render_fused", "trace_", "wf_")):
             tot[(row["Kernel_Name"][:40], row["Counter_Name"])] += float(row["Counter_Value"])
 for k in sorted(tot): print(k[0], k[1], tot[k])
 PY
