@@ -97,7 +97,8 @@ constexpr float kPi = 3.1415926535897932385f;
 constexpr int kNodeFields = 8;        // minx miny minz maxx maxy maxz code order   (float4 / int4 each)
 constexpr int kNodeStrideGlobal = 8;  // float4 per node in HBM (one 128-byte line)
 constexpr int kPrimQuads = 3;         // float4 per primitive record
-constexpr int kShadeQuads = 6;        // float4 per shading record
+constexpr int kShadeQuads = 2;        // float4 per shading record, the part every hit reads
+constexpr int kShadeColdQuads = 4;    // float4 of its other part (smooth, textured or normal-mapped objects only)
 constexpr int kXformFloats = 24;      // rinv[9] anchor[3] trans[3] rot[9]
 
 struct DevImage {
@@ -116,7 +117,8 @@ struct DevCamera {
 struct DevScene {
     const float4* nodes;      // [node_count][8]     node-major
     const float4* prims;      // [object_count][3]
-    const float4* shade;      // [object_count][6]
+    const float4* shade;      // [object_count][2]
+    const float4* shade_cold; // [object_count][4]
     const float* xforms;      // [xform_count][24]
     const float4* mats;       // [material_count][2]
     const float4* texs;       // [texture_count][2]
@@ -756,9 +758,10 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     const float4* pq = sc.prims + h.obj * kPrimQuads;
     const float4* sq = sc.shade + h.obj * kShadeQuads;
     float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
-    float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
+    float4 s0 = sq[0], s1 = sq[1];
     int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
-    int normal_idx = __float_as_int(s1.w);
+    const int packed = __float_as_int(s1.w), flags = packed & 7;
+    int normal_idx = (packed >> 3) - 1;
     const float* X = sc.xforms + (xf >= 0 ? xf : 0) * kXformFloats;
     V3 o = r.o, d = r.d;
     if (xf >= 0) to_object_space(X, r.o, r.d, o, d);
@@ -769,24 +772,29 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     V3 p = o + d * h.t;
     V3 tangent = v3(0, 0, 0), bitangent = v3(0, 0, 0);
     if (type == 2) {
-        float4 s3 = sq[3], s4 = sq[4], s5 = sq[5];
         float w = 1.0f - h.bu - h.bv;
+        // vertex uvs, third vertex normal, tangent frame: only where something reads them
+        float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
+        if (ALWAYS_UV || (flags & 3) || normal_idx >= 0) {
+            const float4* cq = sc.shade_cold + h.obj * kShadeColdQuads;
+            c0 = cq[0]; c1 = cq[1]; c2 = cq[2]; c3 = cq[3];
+        }
         V3 n;
-        if (__float_as_int(s2.w) & 1) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(s2.x, s2.y, s2.z));
+        if (flags & 1) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(c0.x, c0.y, c0.z));
         else n = v3(s0.x, s0.y, s0.z);
         s.front = dot(d, n) < 0.0f;
         s.normal = s.front ? n : -n;
-        if (__float_as_int(s2.w) & 4) {
+        if (flags & 4) {
             // flat triangle without a normal map: the host has stored unit(world normal) in the slot of
             // the second vertex normal; negation commutes with every step of rotating and normalising
             const V3 pre = v3(s1.x, s1.y, s1.z);
             s.unit_normal = s.front ? pre : -pre;
             s.has_unit = true;
         }
-        s.u = w * s3.x + h.bu * s3.z + h.bv * s4.x;
-        s.v = w * s3.y + h.bu * s3.w + h.bv * s4.y;
-        tangent = v3(s4.z, s4.w, s5.x);
-        bitangent = v3(s5.y, s5.z, s5.w);
+        s.u = w * c1.x + h.bu * c1.z + h.bv * c2.x;
+        s.v = w * c1.y + h.bu * c1.w + h.bv * c2.y;
+        tangent = v3(c2.z, c2.w, c3.x);
+        bitangent = v3(c3.y, c3.z, c3.w);
     } else {
         V3 c0 = v3(q0.x, q0.y, q0.z), cd = v3(q1.x, q1.y, q1.z);
         float radius = q0.w;
@@ -795,7 +803,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         s.front = dot(d, outward) < 0.0f;
         s.normal = s.front ? outward : -outward;
         s.u = 0.0f; s.v = 0.0f;
-        if (ALWAYS_UV || (__float_as_int(s2.w) & 2)) {
+        if (ALWAYS_UV || (flags & 2)) {
             float theta = acosf(-outward.y);                             // get_sphere_uv
             float phi = atan2f(-outward.z, outward.x) + kPi;
             s.u = phi / (2 * kPi);

@@ -1548,7 +1548,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         if (oi >= 0 && oi < d->object_count) visit_rank[(size_t)oi] = (int32_t)rank;
     }
     std::vector<float> xforms;
-    std::vector<float> prim_rec((size_t)d->object_count * kPrimQuads * 4, 0.0f), shade_rec((size_t)d->object_count * kShadeQuads * 4, 0.0f);
+    std::vector<float> prim_rec((size_t)d->object_count * kPrimQuads * 4, 0.0f), shade_rec((size_t)d->object_count * kShadeQuads * 4, 0.0f),
+                       cold_rec((size_t)d->object_count * kShadeColdQuads * 4, 0.0f);
     for (int i = 0; i < d->object_count; i++) {
         const crt_object& o = d->objects[i];
         int xf = -1;
@@ -1573,10 +1574,16 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             p[4] = o.p1[0]; p[5] = o.p1[1]; p[6] = o.p1[2];
         }
         p[9] = as_float(xf); p[10] = as_float(o.type); p[11] = as_float(visit_rank[(size_t)i]);
+        // Shading record in two parts.  Hot, 32 bytes, read for every hit: flat normal (or first vertex
+        // normal), material, second vertex normal or the precomputed unit world normal, and normal map +
+        // flags in one word ((normal_idx + 1) << 3 | bit 0 smooth, bit 1 something reads (u, v), bit 2 unit
+        // normal precomputed).  Cold, 64 bytes, only read for smooth, textured or normal-mapped objects:
+        // third vertex normal, vertex uvs, tangent, bitangent.  A flat untextured triangle (every triangle of
+        // a large mesh) costs a quarter of a cache line instead of a whole one per hit.
         float* s = &shade_rec[(size_t)i * kShadeQuads * 4];
+        int32_t flags = (o.shade_smooth ? 1 : 0) | (reads_uv(d, o) ? 2 : 0);
         s[0] = o.n0[0]; s[1] = o.n0[1]; s[2] = o.n0[2]; s[3] = as_float(o.mat_idx);
-        s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2]; s[7] = as_float(o.normal_idx);
-        s[8] = o.n2[0]; s[9] = o.n2[1]; s[10] = o.n2[2]; s[11] = as_float((o.shade_smooth ? 1 : 0) | (reads_uv(d, o) ? 2 : 0));
+        s[4] = o.n1[0]; s[5] = o.n1[1]; s[6] = o.n1[2];
         if (o.type == CRT_OBJ_TRI && !o.shade_smooth && o.normal_idx < 0) {
             // unit(normal) of the normal pass (render.cuh:55), as make_surface() would compute it for a
             // front-facing hit: the flat normal, rotated if the object is transformed, divided by its length
@@ -1584,11 +1591,14 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             if (xf >= 0) n = matvec(o.rotation, n);
             n = unit(n);
             s[4] = n.x; s[5] = n.y; s[6] = n.z;
-            s[11] = as_float(__builtin_bit_cast(int32_t, s[11]) | 4);
+            flags |= 4;
         }
-        s[12] = o.uv0[0]; s[13] = o.uv0[1]; s[14] = o.uv1[0]; s[15] = o.uv1[1];
-        s[16] = o.uv2[0]; s[17] = o.uv2[1]; s[18] = o.tangent[0]; s[19] = o.tangent[1];
-        s[20] = o.tangent[2]; s[21] = o.bitangent[0]; s[22] = o.bitangent[1]; s[23] = o.bitangent[2];
+        s[7] = as_float(((o.normal_idx + 1) << 3) | flags);
+        float* c = &cold_rec[(size_t)i * kShadeColdQuads * 4];
+        c[0] = o.n2[0]; c[1] = o.n2[1]; c[2] = o.n2[2];
+        c[4] = o.uv0[0]; c[5] = o.uv0[1]; c[6] = o.uv1[0]; c[7] = o.uv1[1];
+        c[8] = o.uv2[0]; c[9] = o.uv2[1]; c[10] = o.tangent[0]; c[11] = o.tangent[1];
+        c[12] = o.tangent[2]; c[13] = o.bitangent[0]; c[14] = o.bitangent[1]; c[15] = o.bitangent[2];
     }
     if (xforms.empty()) xforms.assign(kXformFloats, 0.0f);
     std::vector<float> mat_rec((size_t)std::max(1, d->material_count) * 8, 0.0f);
@@ -1730,6 +1740,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     size_t off_nodes = blob.add(node_rec.data(), node_rec.size() * 4);
     size_t off_prims = blob.add(prim_rec.data(), prim_rec.size() * 4);
     size_t off_shade = blob.add(shade_rec.data(), shade_rec.size() * 4);
+    size_t off_cold = blob.add(cold_rec.data(), cold_rec.size() * 4);
     size_t off_xf = blob.add(xforms.data(), xforms.size() * 4);
     size_t off_mats = blob.add(mat_rec.data(), mat_rec.size() * 4);
     size_t off_texs = blob.add(tex_rec.data(), tex_rec.size() * 4);
@@ -1753,6 +1764,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     D.nodes = reinterpret_cast<const float4*>(base + off_nodes);
     D.prims = reinterpret_cast<const float4*>(base + off_prims);
     D.shade = reinterpret_cast<const float4*>(base + off_shade);
+    D.shade_cold = reinterpret_cast<const float4*>(base + off_cold);
     D.xforms = reinterpret_cast<const float*>(base + off_xf);
     D.mats = reinterpret_cast<const float4*>(base + off_mats);
     D.texs = reinterpret_cast<const float4*>(base + off_texs);
