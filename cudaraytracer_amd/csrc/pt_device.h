@@ -279,6 +279,26 @@ __device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3&
     oo = matvec(xf, o - anchor - trans) + anchor;
     od = matvec(xf, d);
 }
+// A primitive's transform index with this bit set: rotation and inverse rotation are exactly the
+// identity matrix (a translated object, or any sphere: the reference anchors a sphere at its
+// centre), only anchor and translation act.  The two matrix products are then left out:
+// 1*x + 0*y + 0*z is x for every finite vector (up to the sign of a zero), so (o - anchor -
+// translation) + anchor and the untouched direction are what hittable.cuh:429-430 computes.
+// PLAIN = 0: the scene has no such transform (known at upload) and the test for it is compiled out.
+constexpr int kXfIdentityRotation = 1 << 30;
+template <int PLAIN = 1>
+__device__ __forceinline__ const float* xform_record(const float* xforms, int xf) {
+    return xforms + (PLAIN ? (xf & ~kXfIdentityRotation) : xf) * kXformFloats;
+}
+__device__ __forceinline__ void to_object_space(const float* X, bool plain, V3 o, V3 d, V3& oo, V3& od) {
+    if (plain) {
+        V3 anchor = v3(X[9], X[10], X[11]), trans = v3(X[12], X[13], X[14]);
+        oo = (o - anchor - trans) + anchor;
+        od = d;
+    } else {
+        to_object_space(X, o, d, oo, od);
+    }
+}
 
 // aabb.cuh:140 -- the reciprocal drops the sign for tiny components (always +1e8)
 __device__ __forceinline__ V3 slab_reciprocal(V3 d, int fast) {
@@ -378,7 +398,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
     const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
     V3 o = r.o, d = r.d;
-    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(S.xform(xf), r.o, r.d, o, d); }
+    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record(S.xforms, xf), (xf & kXfIdentityRotation) != 0, r.o, r.d, o, d); }
     const int before = ts.best.obj;
     if (type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
@@ -605,7 +625,7 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
     return r;
 }
 
-template <int GROUPS, int FAST>
+template <int GROUPS, int FAST, int PLAIN = 1>
 __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax, SectionClock& clk) {
     ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
@@ -653,7 +673,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         V3 o = r.o, d = r.d;
         if constexpr (GROUPS >= 1) { if (group == 1) { o = o1; d = d1; } }
         if constexpr (GROUPS >= 2) { if (group == 2) { o = o2; d = d2; } }
-        if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(L.xforms + xf * kXformFloats, r.o, r.d, o, d); }
+        if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<PLAIN>(L.xforms, xf), PLAIN && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
         if (is_tri) {
             // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
             TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax, FAST);
@@ -753,7 +773,7 @@ struct Surface {
 // ALWAYS_UV = false: the (u, v) of a sphere, an acosf and an atan2f, are only computed for objects
 // on which something reads them (flag bit 1 of the shading record: an image texture under the
 // material or a normal map); the render never looks at them otherwise.
-template <bool ALWAYS_UV>
+template <bool ALWAYS_UV, int PLAIN = 1>
 __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
     const float4* pq = sc.prims + h.obj * kPrimQuads;
     const float4* sq = sc.shade + h.obj * kShadeQuads;
@@ -762,9 +782,10 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
     const int packed = __float_as_int(s1.w), flags = packed & 7;
     int normal_idx = (packed >> 3) - 1;
-    const float* X = sc.xforms + (xf >= 0 ? xf : 0) * kXformFloats;
+    const float* X = xform_record<PLAIN>(sc.xforms, xf >= 0 ? xf : 0);
+    const bool plain = PLAIN && xf >= 0 && (xf & kXfIdentityRotation);
     V3 o = r.o, d = r.d;
-    if (xf >= 0) to_object_space(X, r.o, r.d, o, d);
+    if (xf >= 0) to_object_space(X, plain, r.o, r.d, o, d);
     Surface s;
     s.has_unit = false;
     s.unit_normal = v3(0.0f, 0.0f, 0.0f);
@@ -818,9 +839,14 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     }
     if (xf >= 0) {
         V3 anchor = v3(X[9], X[10], X[11]), trans = v3(X[12], X[13], X[14]);
-        p = matvec(X + 15, p - anchor) + anchor;
-        p = p + trans;
-        s.normal = matvec(X + 15, s.normal);
+        if (plain) {                                                     // hittable.cuh:439-441 with the identity matrix
+            p = (p - anchor) + anchor;
+            p = p + trans;
+        } else {
+            p = matvec(X + 15, p - anchor) + anchor;
+            p = p + trans;
+            s.normal = matvec(X + 15, s.normal);
+        }
     }
     s.p = p;
     if (normal_idx >= 0) {                                               // apply_normal_map

@@ -142,7 +142,7 @@ struct WorkItem {
 // left.  A wave keeps TWO items open: lanes whose path ended take new paths from the `fill`
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
-template <int MODE, int STACK, int GROUPS, int FAST>
+template <int MODE, int STACK, int GROUPS, int FAST, int PLAIN = 1>
 __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(RenderArgs A) {
     constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
     constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
             CRT_PROF(kProfTrace);
             if constexpr (MODE == kModeFlat) {
                 CRT_CLOCK(clk, kSecBox, ray.o.y);
-                h = traverse_flat<GROUPS, FAST>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+                h = traverse_flat<GROUPS, FAST, PLAIN>(FL, A.flat, ray, 0.001f, INFINITY, clk);
             } else {
                 h = ts.result();
             }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
-                sf = make_surface<false>(sc, ray, h);
+                sf = make_surface<false, PLAIN>(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
                 mat_type = __float_as_int(m0.x);
             }
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs A) {
         const float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
         const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
         V3 o = r.o, d = r.d;
-        if (xf >= 0) to_object_space(S.xform(xf), r.o, r.d, o, d);
+        if (xf >= 0) to_object_space(xform_record(S.xforms, xf), (xf & kXfIdentityRotation) != 0, r.o, r.d, o, d);
         Hit h;
         h.t = 0.0f; h.obj = obj; h.bu = 0.0f; h.bv = 0.0f;
         bool ok;
@@ -992,6 +992,7 @@ struct crt_scene {
     int lds_scene_bytes = 0;         // field-major copy of nodes + prims + xforms
     int lds_flat_bytes = 0;          // flat mode: slot records + xforms
     bool can_lds = false, can_flat = false;
+    bool has_plain_xf = false;       // some object's transform has no rotation (kXfIdentityRotation set)
     FlatView flat = {};
     int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
     bool ordered = false;            // walked in the reference's order (a primitive sticks out of its box)
@@ -1159,8 +1160,14 @@ int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
 
 template <int GROUPS>
 void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
-    if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1>), grid, dim3(kBlock), lds, sc->stream, A);
-    else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+    // no transform without a rotation in the scene: the kernel variant without the test for one
+    if (!sc->has_plain_xf) {
+        if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+        else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A);
+    } else {
+        if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, 1>), grid, dim3(kBlock), lds, sc->stream, A);
+        else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A);
+    }
 }
 
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
@@ -1548,6 +1555,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         if (oi >= 0 && oi < d->object_count) visit_rank[(size_t)oi] = (int32_t)rank;
     }
     std::vector<float> xforms;
+    bool has_plain_xf = false;
     std::vector<float> prim_rec((size_t)d->object_count * kPrimQuads * 4, 0.0f), shade_rec((size_t)d->object_count * kShadeQuads * 4, 0.0f),
                        cold_rec((size_t)d->object_count * kShadeColdQuads * 4, 0.0f);
     for (int i = 0; i < d->object_count; i++) {
@@ -1573,7 +1581,10 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             p[0] = o.p0[0]; p[1] = o.p0[1]; p[2] = o.p0[2]; p[3] = o.p2[0];
             p[4] = o.p1[0]; p[5] = o.p1[1]; p[6] = o.p1[2];
         }
-        p[9] = as_float(xf); p[10] = as_float(o.type); p[11] = as_float(visit_rank[(size_t)i]);
+        // transforms without a rotation (translated objects, every sphere) are marked: the kernels then skip the matrix products
+        const int xf_coded = (xf >= 0 && identity9(o.rotation) && identity9(o.rotation_inv)) ? (xf | kXfIdentityRotation) : xf;
+        if (xf_coded != xf) has_plain_xf = true;
+        p[9] = as_float(xf_coded); p[10] = as_float(o.type); p[11] = as_float(visit_rank[(size_t)i]);
         // Shading record in two parts.  Hot, 32 bytes, read for every hit: flat normal (or first vertex
         // normal), material, second vertex normal or the precomputed unit world normal, and normal map +
         // flags in one word ((normal_idx + 1) << 3 | bit 0 smooth, bit 1 something reads (u, v), bit 2 unit
@@ -1798,6 +1809,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
     sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)(stack_entries + 8) * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
     sc->can_flat = can_flat;
+    sc->has_plain_xf = has_plain_xf;
     sc->ordered = ordered;
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
