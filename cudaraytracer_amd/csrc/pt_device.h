@@ -550,12 +550,18 @@ constexpr int kMaxFlatSlots = 64;
 constexpr int kMaxFlatGroups = 2;      // rotations that get their own object-space group
 
 struct FlatView {                      // part of the kernel arguments
-    const float4* boxes;               // [slot_count][2]: {minx,maxx,miny,maxy},{minz,maxz,0,0}
+    const float4* boxes;               // [box_end[last]][2]: {minx,maxx,miny,maxy},{minz,maxz,0,0} of the slots outside cuboids,
+                                       // then, from quad cuboid_quad0 on, the cuboid records: world group 5 quads each (flat_cuboid()),
+                                       // rotated groups 4 quads each (flat_cuboid_shared())
     const float4* slots;               // [slot_count][5]: see pack_slot() on the host
     const int32_t* ent_obj;            // rank in the reference's visiting order -> object index
     const float* group_xf;             // [groups][24] transform of group 1.. (rinv, anchor, trans, rot)
     int32_t slot_count;
-    int32_t group_end[kMaxFlatGroups + 1];   // slots [0,e0) world, [e0,e1) group 1, [e1,e2) group 2
+    // Slots in the order of their box tests: group 0 (world space), group 1, group 2; within a group
+    // the faces of its cuboids, then its other slots.  Running totals per group:
+    int32_t box_end[kMaxFlatGroups + 1];     // box records:    [0,b0) world, [b0,b1) group 1, [b1,b2) group 2
+    int32_t cuboid_end[kMaxFlatGroups + 1];  // cuboid records: [0,c0) world, [c0,c1) group 1, [c1,c2) group 2
+    int32_t cuboid_quad0;
     int32_t groups;
 };
 
@@ -603,6 +609,111 @@ __device__ __forceinline__ void flat_box_range(ConstQuadPtr boxes, int first, in
     for (; s < last; s++) one(s);                        // instructions above count as convergent operations
 }
 
+// A cuboid: up to six slots of one group whose boxes share their planes the way the faces of an
+// axis-aligned box do (the quads of a box object in its own space, the walls of a room).  The box
+// of face "A of axis x" is [thin interval] x [outer y] x [outer z], and so on: 18 distinct plane
+// values instead of 36, and the outer slabs' entry and exit distances are shared by four faces each.
+// Every distance is computed from its plane exactly as flat_box_hit() does and minima / maxima are
+// exact, so each face gets the same bit as its own slab test would give it.
+// Record, 5 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA lo,hi, xB lo,hi} {yA.., yB..} {zA.., zB..};
+// bits are shifted in for the present faces only, in the order xA xB yA yB zA zB.
+template <bool WIDE>
+__device__ __forceinline__ void flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
+    const NativeQuad c0 = rec[0], c1 = rec[1];
+    const int present = __float_as_int(c1.z);
+    const float ax = (c0.x - o.x) * inv.x, bx = (c0.y - o.x) * inv.x;
+    const float ay = (c0.z - o.y) * inv.y, by = (c0.w - o.y) * inv.y;
+    const float az = (c1.x - o.z) * inv.z, bz = (c1.y - o.z) * inv.z;
+    // tmin folded into two of the three entry distances: every face reads at least one of them
+    const float nx = fmaxf(tmin, fminf(ax, bx)), ny = fmaxf(tmin, fminf(ay, by)), nz = fminf(az, bz);
+    const float fx = fmaxf(ax, bx), fy = fmaxf(ay, by), fz = fmaxf(az, bz);
+    auto face = [&](float plane_lo, float plane_hi, float origin, float rcp, float n1, float n2, float f1, float f2) {
+        const float a = (plane_lo - origin) * rcp, b = (plane_hi - origin) * rcp;
+        const float lo = fmaxf(fmaxf(fminf(a, b), n1), n2);
+        const float hi = fminf(fminf(fmaxf(a, b), f1), f2);
+        unsigned long long hit;
+        asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(hit) : "v"(hi), "v"(lo));
+        const unsigned long long carry = shift_in(lo_word, hit);
+        if constexpr (WIDE) (void)shift_in(hi_word, carry);
+    };
+    const NativeQuad tx = rec[2], ty = rec[3], tz = rec[4];
+    if (present & 1) face(tx.x, tx.y, o.x, inv.x, ny, nz, fy, fz);
+    if (present & 2) face(tx.z, tx.w, o.x, inv.x, ny, nz, fy, fz);
+    if (present & 4) face(ty.x, ty.y, o.y, inv.y, nx, nz, fx, fz);
+    if (present & 8) face(ty.z, ty.w, o.y, inv.y, nx, nz, fx, fz);
+    if (present & 16) face(tz.x, tz.y, o.z, inv.z, nx, ny, fx, fy);
+    if (present & 32) face(tz.z, tz.w, o.z, inv.z, nx, ny, fx, fy);
+}
+// A cuboid of a rotated group.  The boxes of a group's slots are not the reference's (they only
+// have to contain their triangles), so here the six face boxes are laid out on FOUR planes per axis,
+// lo-p < lo+p < hi-p < hi+p: outer interval [lo-p, hi+p], face A [lo-p, lo+p], face B [hi-p, hi+p].
+// With LO / HI the entry / exit distance of the outer box and q the distance to a face's inner plane,
+// the face whose outer plane the ray meets first is hit iff the box is hit and LO <= q, the other
+// one iff the box is hit and q <= HI (distances to ordered planes are ordered, rounding is monotone):
+// one inner plane per face instead of a slab test per face.  `pos` = lanes whose reciprocal is
+// positive on the axis (face A is then the near one).
+// Record, 4 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA,xB,yA,yB inner planes} {zA,zB,-,-}.
+template <bool WIDE>
+__device__ __forceinline__ void flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned long long pos_x, unsigned long long pos_y,
+                                                   unsigned long long pos_z, unsigned& lo_word, unsigned& hi_word) {
+    const NativeQuad c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
+    const int present = __float_as_int(c1.z);
+    const float ax = (c0.x - o.x) * inv.x, bx = (c0.y - o.x) * inv.x;
+    const float ay = (c0.z - o.y) * inv.y, by = (c0.w - o.y) * inv.y;
+    const float az = (c1.x - o.z) * inv.z, bz = (c1.y - o.z) * inv.z;
+    const float LO = fmaxf(tmin, fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)));
+    const float HI = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    // a missed box: LO and HI become NaN, which fails both ordered comparisons below
+    const bool box = !(HI < LO);
+    const float lo_box = box ? LO : __builtin_nanf(""), hi_box = box ? HI : __builtin_nanf("");
+    auto axis = [&](float plane_a, float plane_b, float origin, float rcp, unsigned long long pos, int bits) {
+        const float ta = (plane_a - origin) * rcp, tb = (plane_b - origin) * rcp;
+        const float qn = fminf(ta, tb), qf = fmaxf(ta, tb);
+        unsigned long long near_hit, far_hit;
+        asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(near_hit) : "v"(lo_box), "v"(qn));
+        asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(far_hit) : "v"(qf), "v"(hi_box));
+        const unsigned long long swap = (near_hit ^ far_hit) & pos;      // face A: pos ? near : far; face B the other way round
+        if (bits & 1) {
+            const unsigned long long carry = shift_in(lo_word, far_hit ^ swap);
+            if constexpr (WIDE) (void)shift_in(hi_word, carry);
+        }
+        if (bits & 2) {
+            const unsigned long long carry = shift_in(lo_word, near_hit ^ swap);
+            if constexpr (WIDE) (void)shift_in(hi_word, carry);
+        }
+    };
+    if (present == 63) {                                                 // the usual case without the six tests
+        axis(c2.x, c2.y, o.x, inv.x, pos_x, 3);
+        axis(c2.z, c2.w, o.y, inv.y, pos_y, 3);
+        axis(c3.x, c3.y, o.z, inv.z, pos_z, 3);
+    } else {
+        axis(c2.x, c2.y, o.x, inv.x, pos_x, present);
+        axis(c2.z, c2.w, o.y, inv.y, pos_y, present >> 2);
+        axis(c3.x, c3.y, o.z, inv.z, pos_z, present >> 4);
+    }
+}
+// Box tests of one group: its cuboids, then its other slots.  SHARED: the group's cuboids are of the
+// four-planes-per-axis kind (rotated groups), 4 quads each; else 5 quads each.
+template <bool WIDE, bool SHARED>
+__device__ __forceinline__ void flat_group_boxes(const FlatView& F, int g, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
+    ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
+    const int first = g ? F.cuboid_end[g - 1] : 0, last = F.cuboid_end[g];
+    if constexpr (SHARED) {
+        if (first < last) {
+            ConstQuadPtr cuboids = boxes + F.cuboid_quad0 + 5 * F.cuboid_end[0];
+            unsigned long long pos_x, pos_y, pos_z;
+            asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_x) : "v"(inv.x));
+            asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_y) : "v"(inv.y));
+            asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_z) : "v"(inv.z));
+            for (int c = first; c < last; c++) flat_cuboid_shared<WIDE>(cuboids + 4 * (c - F.cuboid_end[0]), o, inv, tmin, pos_x, pos_y, pos_z, lo_word, hi_word);
+        }
+    } else {
+        ConstQuadPtr cuboids = boxes + F.cuboid_quad0;
+        for (int c = first; c < last; c++) flat_cuboid<WIDE>(cuboids + 5 * c, o, inv, tmin, lo_word, hi_word);
+    }
+    flat_box_range<WIDE>(boxes, g ? F.box_end[g - 1] : 0, F.box_end[g], o, inv, tmin, lo_word, hi_word);
+}
+
 struct TriEval {
     bool ok;
     float t, u, v;
@@ -627,13 +738,12 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
 
 template <int GROUPS, int FAST, int PLAIN = 1>
 __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax, SectionClock& clk) {
-    ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
     unsigned cand_lo = 0, cand_hi = 0;
     const bool wide = F.slot_count > 32;                      // uniform over the launch
     const V3 inv0 = slab_reciprocal(r.d, FAST);
-    if (wide) flat_box_range<true>(boxes, 0, F.group_end[0], r.o, inv0, tmin, cand_lo, cand_hi);
-    else flat_box_range<false>(boxes, 0, F.group_end[0], r.o, inv0, tmin, cand_lo, cand_hi);
+    if (wide) flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    else flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
     // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
     V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
     if constexpr (GROUPS >= 1) {
@@ -642,8 +752,8 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         for (int k = 0; k < 15; k++) X[k] = gx[k];
         to_object_space(X, r.o, r.d, o1, d1);
         const V3 inv1 = slab_reciprocal(d1, FAST);
-        if (wide) flat_box_range<true>(boxes, F.group_end[0], F.group_end[1], o1, inv1, tmin, cand_lo, cand_hi);
-        else flat_box_range<false>(boxes, F.group_end[0], F.group_end[1], o1, inv1, tmin, cand_lo, cand_hi);
+        if (wide) flat_group_boxes<true, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
+        else flat_group_boxes<false, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
     }
     if constexpr (GROUPS >= 2) {
         float X[15];
@@ -651,8 +761,8 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         for (int k = 0; k < 15; k++) X[k] = gx[kXformFloats + k];
         to_object_space(X, r.o, r.d, o2, d2);
         const V3 inv2 = slab_reciprocal(d2, FAST);
-        if (wide) flat_box_range<true>(boxes, F.group_end[1], F.group_end[2], o2, inv2, tmin, cand_lo, cand_hi);
-        else flat_box_range<false>(boxes, F.group_end[1], F.group_end[2], o2, inv2, tmin, cand_lo, cand_hi);
+        if (wide) flat_group_boxes<true, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
+        else flat_group_boxes<false, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
     }
 
     Hit best;

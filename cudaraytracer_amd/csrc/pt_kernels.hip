@@ -1471,6 +1471,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     opt.struct_size = (int32_t)sizeof(opt);
     if (opt.accel < CRT_ACCEL_AUTO || opt.accel > CRT_ACCEL_ORDERED) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->accel must be CRT_ACCEL_*");
     if (opt.mode < 0 || opt.mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->mode must be 0..3");
+    if (opt.flat_cuboids < 0 || opt.flat_cuboids > 2) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..2");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
         return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
@@ -1638,13 +1639,15 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     // ---- flat mode (small scenes): box slots, see pt_device.h "flat traversal"
     std::vector<float> flat_box_rec, flat_slot_rec, flat_group_xf;
     std::vector<int32_t> flat_ent_obj;
-    int flat_groups = 0, flat_group_end[kMaxFlatGroups + 1] = {0, 0, 0};
+    int flat_groups = 0, flat_box_end[kMaxFlatGroups + 1] = {0, 0, 0}, flat_cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
+    int flat_cuboid_quad0 = 0, flat_slot_count = 0;
     bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
     if (can_flat) {
         struct Slot {
             int group, xf, type, rank_a, rank_b;
             bool has_b;
             float box[6];     // min xyz, max xyz
+            float raw[6];     // rotated groups: the same before padding
         };
         std::vector<Slot> slots;
         std::vector<int> group_of_xf;      // rotation transform index -> group number (1..)
@@ -1657,6 +1660,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             Slot sl;
             sl.group = 0; sl.xf = xf; sl.type = o.type; sl.rank_a = (int)rank; sl.rank_b = 0; sl.has_b = false;
             for (int a = 0; a < 3; a++) { sl.box[a] = d->bvh.min_bounds[3 * ls + a]; sl.box[3 + a] = d->bvh.max_bounds[3 * ls + a]; }
+            std::memcpy(sl.raw, sl.box, sizeof(sl.raw));
             const bool rotated = !(identity9(o.rotation) && identity9(o.rotation_inv));
             if (o.type == CRT_OBJ_TRI && xf >= 0 && rotated) {
                 // own group per rotation; object-space box of the three vertices, padded
@@ -1676,6 +1680,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                     const float pad = 0.001f + 1e-5f * (std::fabs(lo) + std::fabs(hi));
                     sl.box[a] = lo - pad;
                     sl.box[3 + a] = hi + pad;
+                    sl.raw[a] = lo;
+                    sl.raw[3 + a] = hi;
                 }
             }
             bool merged = false;
@@ -1696,12 +1702,152 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         if (can_flat) {
             flat_groups = (int)group_of_xf.size();
             std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.group < b.group; });
-            for (const Slot& sl : slots) flat_group_end[sl.group] += 1;
-            for (int g = 1; g <= kMaxFlatGroups; g++) flat_group_end[g] += flat_group_end[g - 1];
             for (int g : group_of_xf) flat_group_xf.insert(flat_group_xf.end(), &xforms[(size_t)g * kXformFloats], &xforms[(size_t)(g + 1) * kXformFloats]);
-            for (const Slot& sl : slots) {
-                const float brec[8] = {sl.box[0], sl.box[3], sl.box[1], sl.box[4], sl.box[2], sl.box[5], 0.0f, 0.0f};
-                flat_box_rec.insert(flat_box_rec.end(), brec, brec + 8);
+            // Cuboids (see flat_cuboid() in pt_device.h): sets of four to six slots of a group whose boxes are
+            // [thin interval of one axis] x [the same outer intervals on the other two axes].  A seed slot
+            // taken as a face of axis a fixes the outer intervals of the other two axes; every other
+            // slot that fits them with some interval of its own on a is the opposite face, and the outer
+            // interval of a is whichever value lets the most slots fit as faces of the other axes.
+            struct Cuboid {
+                int group, faces;
+                int face_slot[6];      // xA xB yA yB zA zB, -1 = absent
+                float outer[6];        // xlo xhi ylo yhi zlo zhi
+            };
+            std::vector<Cuboid> cuboids;
+            std::vector<char> in_cuboid(slots.size(), 0);
+            if (opt.flat_cuboids != 2) {
+                auto interval_eq = [](const float* box, int axis, float lo, float hi) { return box[axis] == lo && box[3 + axis] == hi; };
+                for (size_t seed = 0; seed < slots.size(); seed++) {
+                    if (in_cuboid[seed]) continue;
+                    Cuboid best = {};
+                    for (int a = 0; a < 3; a++) {
+                        const int b = (a + 1) % 3, c = (a + 2) % 3;
+                        const float* sb = slots[seed].box;
+                        // candidate outer intervals of axis a: what the possible faces of axes b and c have there
+                        std::vector<size_t> givers;
+                        for (size_t t = 0; t < slots.size(); t++) {
+                            if (t == seed || in_cuboid[t] || slots[t].group != slots[seed].group) continue;
+                            const float* tb = slots[t].box;
+                            const bool fits_b = interval_eq(tb, b, sb[b], sb[3 + b]), fits_c = interval_eq(tb, c, sb[c], sb[3 + c]);
+                            if (fits_b != fits_c) givers.push_back(t);
+                        }
+                        givers.push_back(seed);                                   // stands for "no face on the other axes"
+                        for (size_t giver : givers) {
+                            Cuboid cu = {};
+                            cu.group = slots[seed].group;
+                            for (int k = 0; k < 6; k++) cu.face_slot[k] = -1;
+                            cu.outer[2 * b] = sb[b]; cu.outer[2 * b + 1] = sb[3 + b];
+                            cu.outer[2 * c] = sb[c]; cu.outer[2 * c + 1] = sb[3 + c];
+                            cu.outer[2 * a] = slots[giver].box[a]; cu.outer[2 * a + 1] = slots[giver].box[3 + a];
+                            for (size_t t = 0; t < slots.size(); t++) {
+                                if (in_cuboid[t] || slots[t].group != cu.group) continue;
+                                const float* tb = slots[t].box;
+                                bool fits[3];
+                                for (int x = 0; x < 3; x++) fits[x] = interval_eq(tb, x, cu.outer[2 * x], cu.outer[2 * x + 1]);
+                                int thin_axis = -1;
+                                if (giver == seed) { if (fits[b] && fits[c]) thin_axis = a; }       // outer interval of a unknown: faces of a only
+                                else if (fits[b] && fits[c] && !fits[a]) thin_axis = a;
+                                else if (fits[a] && fits[c] && !fits[b]) thin_axis = b;
+                                else if (fits[a] && fits[b] && !fits[c]) thin_axis = c;
+                                if (thin_axis < 0) continue;
+                                int* pair = &cu.face_slot[2 * thin_axis];
+                                if (pair[0] < 0) pair[0] = (int)t;
+                                else if (pair[1] < 0) pair[1] = (int)t;
+                                else continue;                                    // a third parallel face stays an ordinary slot
+                                cu.faces++;
+                            }
+                            if (cu.faces > best.faces) best = cu;
+                        }
+                    }
+                    // A cuboid of a rotated group is laid out on four planes per axis, lo-p < lo+p < hi-p < hi+p
+                    // (flat_cuboid_shared()): p at least the padding of every box involved, and the cuboid
+                    // thicker than 2p on every axis, else its slots stay as they are.
+                    if (best.faces >= 4 && best.group > 0) {
+                        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                        bool known[3] = {false, false, false}, fits = true;
+                        for (int k = 0; k < 6 && fits; k++) {
+                            if (best.face_slot[k] < 0) continue;
+                            const float* raw = slots[(size_t)best.face_slot[k]].raw;
+                            for (int x = 0; x < 3; x++) {
+                                if (x == k / 2) continue;                          // its own axis: the face plane, below
+                                if (!known[x]) { lo[x] = raw[x]; hi[x] = raw[3 + x]; known[x] = true; }
+                                else if (lo[x] != raw[x] || hi[x] != raw[3 + x]) fits = false;
+                            }
+                        }
+                        int placed[6] = {-1, -1, -1, -1, -1, -1};                  // a face lies in the lower (A) or upper (B) plane of its axis
+                        for (int k = 0; k < 6 && fits; k++) {
+                            if (best.face_slot[k] < 0) continue;
+                            const float* raw = slots[(size_t)best.face_slot[k]].raw;
+                            const int x = k / 2;
+                            int where = -1;
+                            if (known[x] && raw[x] == raw[3 + x] && raw[x] == lo[x]) where = 2 * x;
+                            else if (known[x] && raw[x] == raw[3 + x] && raw[x] == hi[x]) where = 2 * x + 1;
+                            if (where < 0 || placed[where] >= 0) fits = false;
+                            else placed[where] = best.face_slot[k];
+                        }
+                        for (int k = 0; k < 6; k++) best.face_slot[k] = placed[k];
+                        for (int x = 0; x < 3 && fits; x++) {
+                            const float pad = 0.001f + 2e-5f * std::fmax(std::fabs(lo[x]), std::fabs(hi[x]));
+                            if (!(known[x] && hi[x] - lo[x] > 4.0f * pad)) fits = false;
+                            best.outer[2 * x] = lo[x]; best.outer[2 * x + 1] = hi[x];   // unpadded; padded when the record is written
+                        }
+                        if (!fits) best.faces = 0;
+                    }
+                    if (best.faces >= 4) {                                        // below that the shared part costs more than it saves
+                        for (int k = 0; k < 6; k++) if (best.face_slot[k] >= 0) in_cuboid[(size_t)best.face_slot[k]] = 1;
+                        cuboids.push_back(best);
+                    }
+                }
+            }
+            // box-test order = candidate-bit order: per group its cuboid faces, then its other slots
+            std::vector<Slot> ordered_slots;
+            std::vector<float> cuboid_rec;
+            int box_end[kMaxFlatGroups + 1] = {0, 0, 0}, cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
+            for (int g = 0; g <= kMaxFlatGroups; g++) {
+                for (const Cuboid& cu : cuboids) {
+                    if (cu.group != g) continue;
+                    float rec[20] = {0};
+                    int present = 0;
+                    for (int k = 0; k < 6; k++) {
+                        if (cu.face_slot[k] < 0) continue;
+                        present |= 1 << k;
+                        ordered_slots.push_back(slots[(size_t)cu.face_slot[k]]);
+                    }
+                    rec[6] = as_float(present);
+                    if (g == 0) {                                                 // flat_cuboid(): every face keeps its own interval
+                        for (int k = 0; k < 6; k++) rec[k] = cu.outer[k];
+                        for (int k = 0; k < 6; k++) {
+                            if (cu.face_slot[k] < 0) continue;
+                            const Slot& sl = slots[(size_t)cu.face_slot[k]];
+                            rec[8 + 2 * k] = sl.box[k / 2]; rec[8 + 2 * k + 1] = sl.box[3 + k / 2];
+                        }
+                        cuboid_rec.insert(cuboid_rec.end(), rec, rec + 20);
+                    } else {                                                      // flat_cuboid_shared(): four planes per axis
+                        for (int x = 0; x < 3; x++) {
+                            const float lo = cu.outer[2 * x], hi = cu.outer[2 * x + 1];
+                            const float pad = 0.001f + 2e-5f * std::fmax(std::fabs(lo), std::fabs(hi));
+                            rec[2 * x] = lo - pad; rec[2 * x + 1] = hi + pad;
+                            rec[8 + 2 * x] = lo + pad; rec[8 + 2 * x + 1] = hi - pad;
+                        }
+                        cuboid_rec.insert(cuboid_rec.end(), rec, rec + 16);
+                    }
+                    cuboid_end[g]++;
+                }
+                for (size_t k = 0; k < slots.size(); k++) {
+                    if (slots[k].group != g || in_cuboid[k]) continue;
+                    const Slot& sl = slots[k];
+                    const float brec[8] = {sl.box[0], sl.box[3], sl.box[1], sl.box[4], sl.box[2], sl.box[5], 0.0f, 0.0f};
+                    flat_box_rec.insert(flat_box_rec.end(), brec, brec + 8);
+                    ordered_slots.push_back(sl);
+                    box_end[g]++;
+                }
+            }
+            for (int g = 1; g <= kMaxFlatGroups; g++) { box_end[g] += box_end[g - 1]; cuboid_end[g] += cuboid_end[g - 1]; }
+            for (int g = 0; g <= kMaxFlatGroups; g++) { flat_box_end[g] = box_end[g]; flat_cuboid_end[g] = cuboid_end[g]; }
+            flat_cuboid_quad0 = (int)(flat_box_rec.size() / 4);
+            flat_box_rec.insert(flat_box_rec.end(), cuboid_rec.begin(), cuboid_rec.end());
+            flat_slot_count = (int)ordered_slots.size();
+            for (const Slot& sl : ordered_slots) {
                 float rec[kSlotQuads * 4] = {0};
                 const crt_object& A = d->objects[flat_ent_obj[sl.rank_a]];
                 const crt_object& B = d->objects[flat_ent_obj[sl.has_b ? sl.rank_b : sl.rank_a]];
@@ -1815,8 +1961,9 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
     sc->flat.ent_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
     sc->flat.group_xf = reinterpret_cast<const float*>(base + off_fgx);
-    sc->flat.slot_count = can_flat ? (int)(flat_box_rec.size() / 8) : 0;
-    for (int g = 0; g <= kMaxFlatGroups; g++) sc->flat.group_end[g] = flat_group_end[g];
+    sc->flat.slot_count = can_flat ? flat_slot_count : 0;
+    for (int g = 0; g <= kMaxFlatGroups; g++) { sc->flat.box_end[g] = flat_box_end[g]; sc->flat.cuboid_end[g] = flat_cuboid_end[g]; }
+    sc->flat.cuboid_quad0 = flat_cuboid_quad0;
     sc->flat.groups = flat_groups;
     sc->lds_flat_bytes = (int)((size_t)sc->flat.slot_count * kSlotQuads * 16 + xforms.size() * 4);
     sc->mode = opt.mode;
@@ -1891,8 +2038,8 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)],
-                                sc->flat.slot_count, sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
+    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)],
+                                sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
                                 sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
                                 sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");
     if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);

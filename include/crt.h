@@ -200,6 +200,9 @@ typedef struct crt_scene_options {
                                  kernel per bounce, per-path result records: bulk renders reproducible bit for bit;
                                  measured slower than the fused kernel), 0 or 2 = the fused kernel (default) */
     int32_t wavefront_paths;  /* path slots (224 bytes each) of the wavefront buffers; 0 = 67 108 864   */
+    int32_t flat_cuboids;     /* small scenes: 0 or 1 = slots whose boxes share planes like the faces of an axis-aligned
+                                 box (a box object, the walls of a room) are box-tested together (default; same
+                                 candidates, fewer operations), 2 = every slot on its own                */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 
