@@ -101,6 +101,23 @@ constexpr int kShadeQuads = 2;        // float4 per shading record, the part eve
 constexpr int kShadeColdQuads = 4;    // float4 of its other part (smooth, textured or normal-mapped objects only)
 constexpr int kXformFloats = 24;      // rinv[9] anchor[3] trans[3] rot[9]
 
+// What a scene contains, found at upload.  The kernels are compiled for sets of these features (a
+// template argument FEAT): code for a feature outside the set is left out, and a scene runs the
+// variant with the smallest set that covers it.  The results are the same in every variant that
+// covers the scene.
+enum : int {
+    kFeatPlainXf = 1 << 0,      // transforms without a rotation are flagged (kXfIdentityRotation)
+    kFeatSphere = 1 << 1,       // sphere objects
+    kFeatSlotXf = 1 << 2,       // flat mode: a slot whose primitives carry their own transform
+    kFeatWide = 1 << 3,         // flat mode: more than 32 slots
+    kFeatShading = 1 << 4,      // smooth normals, objects whose (u, v) is read, normal maps, checker or image textures
+    kFeatMaterials = 1 << 5,    // metal or dielectric materials
+    kFeatEnvTexture = 1 << 6,   // the environment is not one colour
+    kFeatCamera = 1 << 7,       // orthographic camera, defocus blur, moving spheres (ray time)
+    kFeatAll = 0xff,
+    kFeatBasic = 0              // flat triangles under diffuse materials and lights of one colour, pinhole camera
+};
+
 struct DevImage {
     const uint8_t* pixels;
     int32_t width, height, channels, pad;
@@ -173,6 +190,7 @@ struct Ray {
     V3 o, d;
     float time;
 };
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rng& rng) {
     // sample_square draws three uniforms and uses two (camera.cuh:93-96)
     const float offx = -0.5f + (0.5f - -0.5f) * rng.uniform();
@@ -180,8 +198,8 @@ __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rn
     rng.skip(1);
     V3 on_plane = cam.llc + ((float)i + offx) * cam.du + ((float)j + offy) * cam.dv;
     Ray r;
-    if (cam.type == 0) {                            // perspective_ray (camera.cuh:240-248)
-        if (cam.defocus_angle <= 0.0f) {
+    if (!(FEAT & kFeatCamera) || cam.type == 0) {   // perspective_ray (camera.cuh:240-248)
+        if (!(FEAT & kFeatCamera) || cam.defocus_angle <= 0.0f) {
             r.o = cam.center;
         } else {
             float px, py;
@@ -194,7 +212,7 @@ __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rn
         r.d = cam.w;
     }
     // ray time (camera.cuh:246,264) is only read by moving spheres
-    if (cam.needs_time) r.time = rng.uniform();
+    if ((FEAT & kFeatCamera) && cam.needs_time) r.time = rng.uniform();
     else { r.time = 0.0f; rng.skip(1); }
     return r;
 }
@@ -284,11 +302,11 @@ __device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3&
 // centre), only anchor and translation act.  The two matrix products are then left out:
 // 1*x + 0*y + 0*z is x for every finite vector (up to the sign of a zero), so (o - anchor -
 // translation) + anchor and the untouched direction are what hittable.cuh:429-430 computes.
-// PLAIN = 0: the scene has no such transform (known at upload) and the test for it is compiled out.
+// Without kFeatPlainXf the scene has no such transform and the test for it is compiled out.
 constexpr int kXfIdentityRotation = 1 << 30;
-template <int PLAIN = 1>
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ const float* xform_record(const float* xforms, int xf) {
-    return xforms + (PLAIN ? (xf & ~kXfIdentityRotation) : xf) * kXformFloats;
+    return xforms + ((FEAT & kFeatPlainXf) ? (xf & ~kXfIdentityRotation) : xf) * kXformFloats;
 }
 __device__ __forceinline__ void to_object_space(const float* X, bool plain, V3 o, V3 d, V3& oo, V3& od) {
     if (plain) {
@@ -736,11 +754,11 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
     return r;
 }
 
-template <int GROUPS, int FAST, int PLAIN = 1>
+template <int GROUPS, int FAST, int FEAT = kFeatAll>
 __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax, SectionClock& clk) {
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
     unsigned cand_lo = 0, cand_hi = 0;
-    const bool wide = F.slot_count > 32;                      // uniform over the launch
+    const bool wide = (FEAT & kFeatWide) && F.slot_count > 32;   // uniform over the launch
     const V3 inv0 = slab_reciprocal(r.d, FAST);
     if (wide) flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
     else flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
@@ -772,7 +790,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     while (cand_lo | cand_hi) {
         CRT_PROF(kProfPrim);
         int bit;                                               // any order will do, see consider()
-        if (cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
+        if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
         else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
         const int s = bit;                                     // the LDS copy is stored last slot first
         const float4* rec = L.slots + s * kSlotQuads;
@@ -780,11 +798,21 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         const int meta = __float_as_int(q4.z), xf = __float_as_int(q4.w);
         const int rank_a = meta & 63, rank_b = (meta >> 6) & 63, group = (meta >> 15) & 3;
         const bool has_b = (meta >> 12) & 1, is_tri = ((meta >> 13) & 3) == 2;
+        // the ray of the slot's group, component by component (selects in registers: written with
+        // branches, the compiler may turn the three rays into an indexed array in scratch memory)
         V3 o = r.o, d = r.d;
-        if constexpr (GROUPS >= 1) { if (group == 1) { o = o1; d = d1; } }
-        if constexpr (GROUPS >= 2) { if (group == 2) { o = o2; d = d2; } }
-        if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<PLAIN>(L.xforms, xf), PLAIN && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
-        if (is_tri) {
+        if constexpr (GROUPS >= 1) {
+            const bool g1 = group == 1;
+            o.x = g1 ? o1.x : o.x; o.y = g1 ? o1.y : o.y; o.z = g1 ? o1.z : o.z;
+            d.x = g1 ? d1.x : d.x; d.y = g1 ? d1.y : d.y; d.z = g1 ? d1.z : d.z;
+        }
+        if constexpr (GROUPS >= 2) {
+            const bool g2 = group == 2;
+            o.x = g2 ? o2.x : o.x; o.y = g2 ? o2.y : o.y; o.z = g2 ? o2.z : o.z;
+            d.x = g2 ? d2.x : d.x; d.y = g2 ? d2.y : d.y; d.z = g2 ? d2.z : d.z;
+        }
+        if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
+        if (!(FEAT & kFeatSphere) || is_tri) {
             // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
             TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax, FAST);
             TriEval B = tri_eval(o, d, v3(q0.y, q0.w, q1.y), v3(q1.w, q2.y, q2.w), v3(q3.y, q3.w, q4.y), tmin, tmax, FAST);
@@ -842,8 +870,10 @@ __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, flo
 
 // _texture::value (texture.cuh:313-324).  Checker recursion (texture.cuh:267-274) becomes a
 // walk down the texture indices; the host guarantees the texture graph is acyclic.
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ V3 texture_value(const DevScene& sc, int idx, float u, float v, V3 p) {
     float4 t0 = sc.texs[idx * 2];
+    if (!(FEAT & kFeatShading)) return v3(t0.y, t0.z, t0.w);     // every texture of the scene is one colour
     int type = __float_as_int(t0.x);
     for (int guard = 0; type == 1 && guard < sc.texture_count; guard++) {
         float4 t1 = sc.texs[idx * 2 + 1];
@@ -883,17 +913,19 @@ struct Surface {
 // ALWAYS_UV = false: the (u, v) of a sphere, an acosf and an atan2f, are only computed for objects
 // on which something reads them (flag bit 1 of the shading record: an image texture under the
 // material or a normal map); the render never looks at them otherwise.
-template <bool ALWAYS_UV, int PLAIN = 1>
+template <bool ALWAYS_UV, int FEAT = kFeatAll>
 __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
     const float4* pq = sc.prims + h.obj * kPrimQuads;
     const float4* sq = sc.shade + h.obj * kShadeQuads;
     float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
     float4 s0 = sq[0], s1 = sq[1];
     int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
-    const int packed = __float_as_int(s1.w), flags = packed & 7;
-    int normal_idx = (packed >> 3) - 1;
-    const float* X = xform_record<PLAIN>(sc.xforms, xf >= 0 ? xf : 0);
-    const bool plain = PLAIN && xf >= 0 && (xf & kXfIdentityRotation);
+    const int packed = __float_as_int(s1.w);
+    // without kFeatShading every object is a flat triangle without a normal map (flag bit 2) or a sphere
+    const int flags = (FEAT & kFeatShading) ? (packed & 7) : 4;
+    const int normal_idx = (FEAT & kFeatShading) ? (packed >> 3) - 1 : -1;
+    const float* X = xform_record<FEAT>(sc.xforms, xf >= 0 ? xf : 0);
+    const bool plain = (FEAT & kFeatPlainXf) && xf >= 0 && (xf & kXfIdentityRotation);
     V3 o = r.o, d = r.d;
     if (xf >= 0) to_object_space(X, plain, r.o, r.d, o, d);
     Surface s;
@@ -902,7 +934,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     s.mat = __float_as_int(s0.w);
     V3 p = o + d * h.t;
     V3 tangent = v3(0, 0, 0), bitangent = v3(0, 0, 0);
-    if (type == 2) {
+    if (!(FEAT & kFeatSphere) || type == 2) {
         float w = 1.0f - h.bu - h.bv;
         // vertex uvs, third vertex normal, tangent frame: only where something reads them
         float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
@@ -922,10 +954,13 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
             s.unit_normal = s.front ? pre : -pre;
             s.has_unit = true;
         }
-        s.u = w * c1.x + h.bu * c1.z + h.bv * c2.x;
-        s.v = w * c1.y + h.bu * c1.w + h.bv * c2.y;
-        tangent = v3(c2.z, c2.w, c3.x);
-        bitangent = v3(c3.y, c3.z, c3.w);
+        s.u = 0.0f; s.v = 0.0f;
+        if (FEAT & kFeatShading) {
+            s.u = w * c1.x + h.bu * c1.z + h.bv * c2.x;
+            s.v = w * c1.y + h.bu * c1.w + h.bv * c2.y;
+            tangent = v3(c2.z, c2.w, c3.x);
+            bitangent = v3(c3.y, c3.z, c3.w);
+        }
     } else {
         V3 c0 = v3(q0.x, q0.y, q0.z), cd = v3(q1.x, q1.y, q1.z);
         float radius = q0.w;
@@ -934,7 +969,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         s.front = dot(d, outward) < 0.0f;
         s.normal = s.front ? outward : -outward;
         s.u = 0.0f; s.v = 0.0f;
-        if (ALWAYS_UV || (flags & 2)) {
+        if (ALWAYS_UV || ((FEAT & kFeatShading) && (flags & 2))) {
             float theta = acosf(-outward.y);                             // get_sphere_uv
             float phi = atan2f(-outward.z, outward.x) + kPi;
             s.u = phi / (2 * kPi);
@@ -1077,6 +1112,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
 // coop_sphere_sample): `rv` is the random unit vector for a lambertian surface, the in-sphere
 // vector for a metal.  Returns false when the material does not scatter (light, or a metal
 // bounce that points into the surface).
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, const Surface& s, float4 m0, V3 rv, Rng& rng, V3& attenuation, Ray& out) {
     int type = __float_as_int(m0.x);
     out.time = in.time;
@@ -1085,9 +1121,10 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.normal;
         out.o = s.p + s.normal * 0.001f;
         out.d = dir;
-        attenuation = texture_value(sc, __float_as_int(m0.y), s.u, s.v, s.p);
+        attenuation = texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
         return true;
     }
+    if (!(FEAT & kFeatMaterials)) return false;                // neither metal nor glass in the scene: a light
     if (type == 1) {                                           // metal :311-322
         float4 m1 = sc.mats[s.mat * 2 + 1];
         V3 unit_dir = unit(in.d);
@@ -1121,15 +1158,17 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
 }
 
 // material::emit (material.cuh:375-381)
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
     float4 m0 = sc.mats[s.mat * 2];
-    if (__float_as_int(m0.x) == 3) return texture_value(sc, __float_as_int(m0.y), s.u, s.v, s.p);
+    if (__float_as_int(m0.x) == 3) return texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
     return v3(0.0f, 0.0f, 0.0f);
 }
 // Environment lookup on a miss (render.cuh:77-82)
+template <int FEAT = kFeatAll>
 __device__ __forceinline__ V3 environment(const DevScene& sc, V3 dir) {
     float4 t0 = sc.texs[sc.background_index * 2];
-    if (__float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
+    if (!(FEAT & kFeatEnvTexture) || __float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
     V3 p = unit(dir);
     float theta = acosf(-p.y);
     float phi = atan2f(-p.z, p.x) + kPi;

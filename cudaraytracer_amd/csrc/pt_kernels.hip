@@ -142,7 +142,7 @@ struct WorkItem {
 // left.  A wave keeps TWO items open: lanes whose path ended take new paths from the `fill`
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
-template <int MODE, int STACK, int GROUPS, int FAST, int PLAIN = 1>
+template <int MODE, int STACK, int GROUPS, int FAST, int FEAT = kFeatAll>
 __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(RenderArgs A) {
     constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
     constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
                         pixoff = fill_buffer * kAccFloatsPerTile + pix;
                         rng.init(pj * sc.width + pi, sample);
-                        ray = camera_ray(*lds_cam, pi, pj, rng);
+                        ray = camera_ray<FEAT>(*lds_cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
                         pend_albedo = v3(0, 0, 0);
                         bounces = 0;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
             CRT_PROF(kProfTrace);
             if constexpr (MODE == kModeFlat) {
                 CRT_CLOCK(clk, kSecBox, ray.o.y);
-                h = traverse_flat<GROUPS, FAST, PLAIN>(FL, A.flat, ray, 0.001f, INFINITY, clk);
+                h = traverse_flat<GROUPS, FAST, FEAT>(FL, A.flat, ray, 0.001f, INFINITY, clk);
             } else {
                 h = ts.result();
             }
@@ -311,21 +311,21 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
-                sf = make_surface<false, PLAIN>(sc, ray, h);
+                sf = make_surface<false, FEAT>(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
                 mat_type = __float_as_int(m0.x);
             }
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
         CRT_CLOCK(clk, kSecSample, sf.p.x);
-        const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
+        const V3 rv = coop_sphere_sample(mat_type == 0 || ((FEAT & kFeatMaterials) && mat_type == 1), (FEAT & kFeatMaterials) && mat_type == 1, rng, coop_pub, coop_res, lane);
         V3 rv_dep = rv;
         CRT_CLOCK(clk, kSecScatter, rv_dep.x);
         if (ready) {
             if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
-                if (scatter_with(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
+                if (scatter_with<FEAT>(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         pend_albedo = attenuation;
                         V3 n = sf.unit_normal;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
                     if (bounces >= sc.max_bounces) alive = false;   // exhausted: col = albedo = 0 (render.cuh:96-97)
                     else if constexpr (MODE != kModeFlat) { ts.begin(INFINITY, sc.root_entry); walking = true; }
                 } else {                                             // render.cuh:64-74
-                    V3 emitted = emit(sc, sf);
+                    V3 emitted = emit<FEAT>(sc, sf);
                     V3 c = throughput * emitted;
                     acc_add3<kTilePixels>(acc, 0, pixoff, c);
                     V3 alb = pend_albedo;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
-                V3 c = throughput * environment(sc, ray.d);
+                V3 c = throughput * environment<FEAT>(sc, ray.d);
                 acc_add3<kTilePixels>(acc, 0, pixoff, c);
                 V3 alb = pend_albedo;
                 if (bounces == 0) {
@@ -992,7 +992,7 @@ struct crt_scene {
     int lds_scene_bytes = 0;         // field-major copy of nodes + prims + xforms
     int lds_flat_bytes = 0;          // flat mode: slot records + xforms
     bool can_lds = false, can_flat = false;
-    bool has_plain_xf = false;       // some object's transform has no rotation (kXfIdentityRotation set)
+    int features = kFeatAll;         // kFeat* bits of what the scene contains (selects the kernel variant)
     FlatView flat = {};
     int mode = 0;                    // 0 auto, 1 tree in HBM, 2 tree in LDS, 3 flat
     bool ordered = false;            // walked in the reference's order (a primitive sticks out of its box)
@@ -1158,16 +1158,17 @@ int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     return CRT_OK;
 }
 
+template <int GROUPS, int FEAT>
+void launch_flat_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
+    if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
+    else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
+}
 template <int GROUPS>
 void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
-    // no transform without a rotation in the scene: the kernel variant without the test for one
-    if (!sc->has_plain_xf) {
-        if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, 0>), grid, dim3(kBlock), lds, sc->stream, A);
-        else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, 0>), grid, dim3(kBlock), lds, sc->stream, A);
-    } else {
-        if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, 1>), grid, dim3(kBlock), lds, sc->stream, A);
-        else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, 1>), grid, dim3(kBlock), lds, sc->stream, A);
-    }
+    // the variant compiled for the smallest feature set that covers the scene
+    if ((sc->features & ~kFeatBasic) == 0) launch_flat_feat<GROUPS, kFeatBasic>(sc, A, grid, lds);
+    else if ((sc->features & kFeatPlainXf) == 0) launch_flat_feat<GROUPS, kFeatAll & ~kFeatPlainXf>(sc, A, grid, lds);
+    else launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds);
 }
 
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
@@ -1471,6 +1472,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     opt.struct_size = (int32_t)sizeof(opt);
     if (opt.accel < CRT_ACCEL_AUTO || opt.accel > CRT_ACCEL_ORDERED) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->accel must be CRT_ACCEL_*");
     if (opt.mode < 0 || opt.mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->mode must be 0..3");
+    if (opt.general_kernel < 0 || opt.general_kernel > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->general_kernel must be 0 or 1");
     if (opt.flat_cuboids < 0 || opt.flat_cuboids > 2) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..2");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
@@ -1641,6 +1643,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     std::vector<int32_t> flat_ent_obj;
     int flat_groups = 0, flat_box_end[kMaxFlatGroups + 1] = {0, 0, 0}, flat_cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
     int flat_cuboid_quad0 = 0, flat_slot_count = 0;
+    bool flat_slot_xf = false;       // some flat slot's primitives carry their own transform
     bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
     if (can_flat) {
         struct Slot {
@@ -1862,6 +1865,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                 const int32_t meta = sl.rank_a | (sl.rank_b << 6) | ((sl.has_b ? 1 : 0) << 12) | (sl.type << 13) | (sl.group << 15);
                 rec[18] = as_float(meta);
                 rec[19] = as_float(sl.xf);
+                if (sl.xf >= 0) flat_slot_xf = true;
                 flat_slot_rec.insert(flat_slot_rec.end(), rec, rec + kSlotQuads * 4);
             }
         }
@@ -1955,8 +1959,26 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     // keep a block (pass sums + stacks + scene copy) under 40 KB so that four blocks still fit a CU
     sc->can_lds = (size_t)sc->lds_scene_bytes + (size_t)(stack_entries + 8) * kBlock * 4 + (size_t)kWaves * wave_lds_bytes(kModeTreeLds) <= 40 * 1024;
     sc->can_flat = can_flat;
-    sc->has_plain_xf = has_plain_xf;
     sc->ordered = ordered;
+    {
+        int feat = 0;
+        if (has_plain_xf) feat |= kFeatPlainXf;
+        if (flat_slot_xf || !can_flat) feat |= kFeatSlotXf;
+        if (flat_slot_count > 32) feat |= kFeatWide;
+        for (int i = 0; i < d->object_count; i++) {
+            const crt_object& o = d->objects[i];
+            if (o.type != CRT_OBJ_TRI) feat |= kFeatSphere;
+            if (o.shade_smooth || o.normal_idx >= 0 || reads_uv(d, o)) feat |= kFeatShading;
+        }
+        for (int i = 0; i < d->texture_count; i++)
+            if (d->textures[i].type != CRT_TEX_SOLID_COLOR) feat |= kFeatShading;
+        for (int i = 0; i < d->material_count; i++)
+            if (d->materials[i].type == CRT_MAT_METAL || d->materials[i].type == CRT_MAT_DIELECTRIC) feat |= kFeatMaterials;
+        if (d->textures[d->background_index].type != CRT_TEX_SOLID_COLOR) feat |= kFeatEnvTexture;
+        if (c.type != 0 || c.defocus_angle > 0.0f || D.cam.needs_time) feat |= kFeatCamera;
+        if (opt.general_kernel == 1) feat = kFeatAll;
+        sc->features = feat;
+    }
     sc->flat.boxes = reinterpret_cast<const float4*>(base + off_fbox);
     sc->flat.slots = reinterpret_cast<const float4*>(base + off_fslot);
     sc->flat.ent_obj = reinterpret_cast<const int32_t*>(base + off_fobj);
@@ -2038,7 +2060,7 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)],
+    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%02x slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
                                 sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
                                 sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
                                 sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");

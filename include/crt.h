@@ -203,6 +203,9 @@ typedef struct crt_scene_options {
     int32_t flat_cuboids;     /* small scenes: 0 or 1 = slots whose boxes share planes like the faces of an axis-aligned
                                  box (a box object, the walls of a room) are box-tested together (default; same
                                  candidates, fewer operations), 2 = every slot on its own                */
+    int32_t general_kernel;   /* 1: always run the kernel variant compiled for every scene feature (spheres, textures,
+                                 metal and glass, camera kinds ...) instead of the one compiled for just what the
+                                 scene contains; same results, for comparison                         */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 
