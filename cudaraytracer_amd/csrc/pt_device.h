@@ -411,14 +411,14 @@ struct TreeState {
     __device__ __forceinline__ Hit result() const { Hit h = best; h.obj = best_obj; return h; }
 };
 
-template <int FAST, class Mem>
+template <int FAST, int FEAT = kFeatAll, class Mem>
 __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, float tmin, TreeState& ts) {
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
     const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
     V3 o = r.o, d = r.d;
-    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record(S.xforms, xf), (xf & kXfIdentityRotation) != 0, r.o, r.d, o, d); }
+    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(S.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
     const int before = ts.best.obj;
-    if (type == 2) {
+    if (!(FEAT & kFeatSphere) || type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
         const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, FAST, t, bu, bv);
         consider(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
 //   * leaf candidates are tested, one per lane, once at least `prim_batch` lanes hold some (or
 //     nobody can take a node step): the long intersection code then runs for a batch of lanes
 //     instead of the one or two that happen to reach a leaf in a given round.
-template <int FAST, class Mem>
+template <int FAST, int FEAT = kFeatAll, class Mem>
 __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin, TreeState& ts, bool& walking, LaneStack stk, int min_active, int prim_batch) {
     const V3 inv = slab_reciprocal(r.d, FAST);
     const float ix = inv.x, iy = inv.y, iz = inv.z;
@@ -511,7 +511,7 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 // an earlier candidate may have shrunk the interval below this box's entry
                 if (!(ts.best.t < lo)) {
                     CRT_PROF(kProfPrim);
-                    tree_prim<FAST>(S, code, r, tmin, ts);
+                    tree_prim<FAST, FEAT>(S, code, r, tmin, ts);
                 }
             }
         }

@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
             CRT_CLOCK(clk, kSecNode, ray.o.y);
             const int living = __builtin_popcountll(__ballot(alive));
             const int ready_target = max(1, living * A.ready_percent / 100);
-            if constexpr (MODE == kModeTreeLds) tree_run<FAST>(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
-            else tree_run<FAST>(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            if constexpr (MODE == kModeTreeLds) tree_run<FAST, FEAT>(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
+            else tree_run<FAST, FEAT>(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
             ready = alive && !walking;
         }
         if (ready) {
@@ -1145,17 +1145,23 @@ int kernel_mode(const crt_scene* sc) {
     }
 }
 
-template <int STACK, int FAST>
-int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
+template <int STACK, int FAST, int FEAT>
+int launch_tree_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)(STACK + 8) * kBlock * sizeof(int);
     if (mode == kModeTreeLds) {
         lds += (size_t)sc->lds_scene_bytes;
-        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0, FAST>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeLds, STACK, 0, FAST, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
     } else {
-        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK, 0, FAST>), grid, dim3(kBlock), lds, sc->stream, A);
+        hipLaunchKernelGGL((render_fused<kModeTreeGlobal, STACK, 0, FAST, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
     }
     CRT_HIP(hipGetLastError());
     return CRT_OK;
+}
+template <int STACK, int FAST>
+int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
+    // the flat mode's feature bits say nothing about a tree walk
+    if ((sc->features & ~(kFeatSlotXf | kFeatWide)) == 0) return launch_tree_feat<STACK, FAST, kFeatBasic>(sc, A, grid, mode);
+    return launch_tree_feat<STACK, FAST, kFeatAll>(sc, A, grid, mode);
 }
 
 template <int GROUPS, int FEAT>
