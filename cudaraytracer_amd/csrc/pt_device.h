@@ -143,6 +143,7 @@ struct DevScene {
     int32_t node_count, object_count, xform_count, material_count, texture_count, background_index;
     int32_t width, height, max_bounces;
     int32_t root_entry;       // stack entry of BVH node 0: leafy flag in bit 0
+    int32_t order_flip;       // see SceneGlobal::order_flip
     int32_t fast_rcp;         // the host proved reciprocal()'s fast form exact for this scene (selects the kernel variant)
     DevCamera cam;
 };
@@ -225,6 +226,7 @@ struct SceneGlobal {
     const float4* prims;
     const float* xforms;
     int root_entry;        // stack entry of node 0
+    int order_flip;        // 15: rays towards -z read a node's slot order backwards; 0: one order for every ray (reference-order walk)
     __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[node * kNodeStrideGlobal + field]; }
     __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[obj * kPrimQuads + q]; }
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
@@ -235,6 +237,7 @@ struct SceneLds {
     const float* xforms;
     int node_count, object_count;
     int root_entry;
+    int order_flip;
     __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[field * node_count + node]; }
     __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[q * object_count + obj]; }
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
@@ -278,6 +281,13 @@ struct Hit {
     float bu, bv;  // triangle barycentrics
 };
 
+// word = (word << 1) | (this lane's bit of `in`), and the bit shifted out goes to this lane's
+// bit of the result: one add-with-carry, the compare result never leaves the scalar mask.
+__device__ __forceinline__ unsigned long long shift_in(unsigned& word, unsigned long long in) {
+    unsigned long long out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(word), "=s"(out) : "v"(word), "s"(in));
+    return out;
+}
 // 1.0f / x.  With `fast` set (a compile-time constant at every call site): v_rcp_f32 plus one Newton step (two FMAs) instead of the general
 // division sequence.  For every float with 2^-100 <= |x| <= 2^100 that is bit-identical to the
 // IEEE quotient (checked over all 2^32 inputs on gfx950, tools/ubench/rcp_exhaustive.hip).  The
@@ -449,6 +459,16 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
     const int ny = iy < 0.0f ? 4 : 1, fy = 5 - ny;
     const int nz = iz < 0.0f ? 5 : 2, fz = 7 - nz;
     const int octant = (ix < 0.0f ? 1 : 0) | (iy < 0.0f ? 2 : 0) | (iz < 0.0f ? 4 : 0);
+    // A node's last quad: {order of octants 0,1 | order of octants 2,3 | leaf slots (bits 0-3) and
+    // internal slots (bits 4-7) | -}.  An octant's order is 16 bits: for slot i, bits 4i..4i+3 are
+    // the slots visited AFTER slot i (farther along the octant's diagonal).  Octants 4-7 (rays
+    // towards -z) are the mirror images of octants 3-0 and read their entry backwards: the slots
+    // visited after i are then the others (and i itself, taken off again through `self`).
+    const unsigned flip = (octant & 4) ? (unsigned)S.order_flip : 0u;
+    const int self = -(int)(flip & 1u);
+    const int oct_entry = (octant & 4) ? (octant ^ 7) : octant;
+    const bool oct_word = (oct_entry & 2) != 0;
+    const int oct_shift = (oct_entry & 1) * 16;
 
     while (true) {                                                  // wave-uniform
         const bool node_step = walking && ts.node >= 0 && !((ts.node & 1) && ts.leaf_mask);
@@ -464,9 +484,9 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
             const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
             const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
             float los[4];
-            unsigned push_mask = 0, leaf_hits = 0;
+            unsigned hit_mask = 0;                                  // bit i: the ray meets slot i's box before the closest hit so far
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 3; i >= 0; i--) {
                 float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
                 float lo = fmaxf(tmin, t0), hi = fminf(ts.best.t, t1);
                 t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
@@ -474,23 +494,37 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
                 lo = fmaxf(lo, t0); hi = fminf(hi, t1);
                 los[i] = lo;
-                if (!(hi < lo)) {
-                    if (codes[i] >= 0) leaf_hits |= 1u << i;
-                    else if (codes[i] < -1) push_mask |= 1u << i;
-                }
+                unsigned long long hit;                             // !(hi < lo), from the compare's lane mask straight into the bit word
+                asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(hit) : "v"(hi), "v"(lo));
+                (void)shift_in(hit_mask, hit);
             }
-            // internal children: farthest first, so that the nearest is popped first
+            // (all three words are read here: used under the branch only, the two order words would be
+            // fetched by a load of their own after the box tests)
+            unsigned kinds = (unsigned)__float_as_int(orderf.z);
+            unsigned order = (unsigned)__float_as_int(oct_word ? orderf.y : orderf.x) >> oct_shift;
+            asm volatile("" : "+v"(kinds), "+v"(order));
+            const unsigned leaf_hits = hit_mask & kinds & 15u, push_mask = hit_mask & (kinds >> 4);
+            // internal children onto the stack, farthest first, so that the nearest is popped first:
+            // a slot's place above the old top is the number of pushed slots visited after it
             if (push_mask) {
-                const unsigned word = (unsigned)__float_as_int(octant < 4 ? orderf.x : orderf.y);
-                const unsigned order = (word >> ((octant & 3) * 8)) & 0xffu;      // 4 x 2 bits, near to far
+                if (ts.sp + 4 <= stk.lds_entries) {
+                    // every slot writes, without a branch: the ones that are not pushed to a word above the new top
 #pragma unroll
-                for (int k = 3; k >= 0; k--) {
-                    const unsigned slot = (order >> (2 * k)) & 3u;
-                    if ((push_mask >> slot) & 1u) {
-                        const int code = slot == 0 ? codes[0] : (slot == 1 ? codes[1] : (slot == 2 ? codes[2] : codes[3]));
-                        stk.put(ts.sp++, -code - 2);
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned after = ((order >> (4 * i)) & 15u) ^ flip;
+                        const int place = __builtin_popcount(after & push_mask) + self;
+                        const bool pushed = (push_mask >> i) & 1u;
+                        stk.base[(ts.sp + (pushed ? place : 3)) * stk.stride] = -codes[i] - 2;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned after = ((order >> (4 * i)) & 15u) ^ flip;
+                        const int place = __builtin_popcount(after & push_mask) + self;
+                        if ((push_mask >> i) & 1u) stk.put(ts.sp + place, -codes[i] - 2);
                     }
                 }
+                ts.sp += __builtin_popcount(push_mask);
             }
             if (leaf_hits) {                                        // only reached with no candidates pending
                 ts.leaf_mask = leaf_hits;
@@ -603,13 +637,6 @@ __device__ __forceinline__ unsigned long long flat_box_hit(NativeQuad b0, Native
     unsigned long long hit;
     asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(hit) : "v"(hi), "v"(lo));
     return hit;
-}
-// word = (word << 1) | (this lane's bit of `in`), and the bit shifted out goes to this lane's
-// bit of the result: one add-with-carry, the compare result never leaves the scalar mask.
-__device__ __forceinline__ unsigned long long shift_in(unsigned& word, unsigned long long in) {
-    unsigned long long out;
-    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(word), "=s"(out) : "v"(word), "s"(in));
-    return out;
 }
 // Box tests of slots [first, last) -> bits shifted into (hi:lo) from the right, so that slot s
 // ends up at bit (slot_count-1-s): the first slot is the highest set bit.  WIDE = more than 32

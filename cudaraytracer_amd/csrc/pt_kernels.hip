@@ -94,7 +94,7 @@ __device__ __forceinline__ SceneLds stage_scene_in_lds(const float4* nodes, int 
     }
     for (int i = threadIdx.x; i < nx * kXformFloats; i += kBlock) lx[i] = xforms[i];
     SceneLds m;
-    m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no; m.root_entry = 0;
+    m.nodes = ln; m.prims = lp; m.xforms = lx; m.node_count = nn; m.object_count = no; m.root_entry = 0; m.order_flip = 0;
     return m;
 }
 
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(Ren
     for (int k = 0; k < kAccFloatsPerWave / 64; k++) acc[k * 64 + lane] = 0.0f;
 
     SceneGlobal SG;
-    SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms; SG.root_entry = sc.root_entry;
+    SG.nodes = sc.nodes; SG.prims = sc.prims; SG.xforms = sc.xforms; SG.root_entry = sc.root_entry; SG.order_flip = sc.order_flip;
     SceneLds SL = {};
-    if constexpr (MODE == kModeTreeLds) { SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene); SL.root_entry = sc.root_entry; }
+    if constexpr (MODE == kModeTreeLds) { SL = stage_scene_in_lds(sc.nodes, sc.node_count, sc.prims, sc.object_count, sc.xforms, sc.xform_count, lds_scene); SL.root_entry = sc.root_entry; SL.order_flip = sc.order_flip; }
     FlatLds FL = {};
     if constexpr (MODE == kModeFlat) FL = stage_flat_in_lds(A.flat, sc.xforms, sc.xform_count, lds_scene);
     __syncthreads();
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(
     const DevScene& sc = A.sc;
     const int lane = threadIdx.x & 63;
     SceneGlobal S;
-    S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+    S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
     LaneStack stk;
     stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
     stk.stride = kBlock;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
             if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
         } else {
             SceneGlobal S;
-            S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+            S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
             LaneStack stk;
             stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
             stk.stride = kBlock;
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs A) {
         for (int k = 0; k < 11; k++) out[k] = 0.0f;
         if (obj < 0 || obj >= sc.object_count) return;
         SceneGlobal S;
-        S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry;
+        S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
         const float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
         const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
         V3 o = r.o, d = r.d;
@@ -1530,30 +1530,44 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             int32_t code = o >= 0 ? o : (c >= 0 ? -(2 * c + (accel_leafy(c) ? 1 : 0)) - 2 : -1);
             rec[6 * 4 + i] = as_float(code);
         }
-        // Visiting order of the four slots for each of the 8 direction octants (bit 0/1/2 set:
-        // the ray runs towards -x/-y/-z): slots sorted by their box centre along the octant's
-        // diagonal, nearest first; 2 bits per slot, one byte per octant.
-        // A scene that has to be walked in the reference's order (bvh.cuh:391-418: children pushed
-        // in slot order, popped last-in first-out) gets "3,2,1,0" for every octant.
+        // Visiting order of the four slots for the direction octants 0-3 (bit 0/1 set: the ray runs
+        // towards -x/-y; +z): slots sorted by their box centre along the octant's diagonal, nearest
+        // first.  Stored per octant as 16 bits, for slot i in bits 4i..4i+3 the slots that come AFTER
+        // it.  Octant 7-o is the mirror image of octant o and reads o's entry backwards
+        // (DevScene::order_flip = 15).  A scene that has to be walked in the reference's order
+        // (bvh.cuh:391-418: children pushed in slot order, popped last-in first-out) gets "3,2,1,0"
+        // for every octant and order_flip = 0.  Third word: leaf slots (bits 0-3), internal slots (bits 4-7).
         uint32_t words[2] = {0, 0};
-        if (ordered) words[0] = words[1] = 0x1b1b1b1bu;
-        for (int oct = 0; oct < 8 && !ordered; oct++) {
+        for (int oct = 0; oct < 4; oct++) {
             float key[4];
-            int idx[4] = {0, 1, 2, 3};
-            for (int i = 0; i < 4; i++) {
-                float k = 0.0f;
-                for (int a = 0; a < 3; a++) {
-                    const float c = 0.5f * (an.lo[i][a] + an.hi[i][a]);
-                    k += ((oct >> a) & 1) ? -c : c;
+            int idx[4] = {3, 2, 1, 0};
+            if (!ordered) {
+                for (int i = 0; i < 4; i++) {
+                    idx[i] = i;
+                    float k = 0.0f;
+                    for (int a = 0; a < 3; a++) {
+                        const float c = 0.5f * (an.lo[i][a] + an.hi[i][a]);
+                        k += ((oct >> a) & 1) ? -c : c;
+                    }
+                    key[i] = std::isfinite(k) ? k : INFINITY;            // empty slots last
                 }
-                key[i] = std::isfinite(k) ? k : INFINITY;            // empty slots last
+                std::stable_sort(idx, idx + 4, [&](int a, int b) { return key[a] < key[b]; });
             }
-            std::stable_sort(idx, idx + 4, [&](int a, int b) { return key[a] < key[b]; });
-            const uint32_t byte = (uint32_t)(idx[0] | (idx[1] << 2) | (idx[2] << 4) | (idx[3] << 6));
-            words[oct >> 2] |= byte << ((oct & 3) * 8);
+            uint32_t entry = 0, after = 0;
+            for (int r = 3; r >= 0; r--) {
+                entry |= after << (4 * idx[r]);
+                after |= 1u << idx[r];
+            }
+            words[oct >> 1] |= entry << ((oct & 1) * 16);
+        }
+        uint32_t kinds = 0;
+        for (int i = 0; i < 4; i++) {
+            if (an.object[i] >= 0) kinds |= 1u << i;
+            else if (an.child[i] >= 0) kinds |= 16u << i;
         }
         rec[7 * 4 + 0] = as_float((int32_t)words[0]);
         rec[7 * 4 + 1] = as_float((int32_t)words[1]);
+        rec[7 * 4 + 2] = as_float((int32_t)kinds);
     }
     // position of every object in the reference's leaf visiting order (tie rule of the closest hit)
     std::vector<int> leaf_slots;
@@ -1946,6 +1960,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     D.height = d->render.image_height;
     D.max_bounces = d->render.max_bounces;
     D.root_entry = accel_leafy(0) ? 1 : 0;
+    D.order_flip = ordered ? 0 : 15;
     D.fast_rcp = fast_reciprocal_is_exact(d) ? 1 : 0;
     if (opt.ieee_division) D.fast_rcp = 0;
     const crt_camera& c = d->camera;
