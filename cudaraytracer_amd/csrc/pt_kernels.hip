@@ -31,21 +31,31 @@
 
 namespace crt {
 
-#ifndef CRT_FUSED_WAVES_PER_SIMD
-#define CRT_FUSED_WAVES_PER_SIMD 4    // register budget of render_fused: 512 / 4 = 128 VGPRs
+// Waves per SIMD a kernel variant is compiled for (its register budget is 512 / waves VGPRs) and the
+// persistent grid is sized for.  The flat kernel is bound by instruction issue with many short
+// dependent chains: it gains from every resident wave until spills set in (Cornell: 9.5 ms at four
+// waves, 8.4 at five, 8.2 at six, 9.1 at seven); its variant for basic scenes needs 82-92 registers,
+// the general one about 110.  The tree walks need all 128.
+#ifndef CRT_FLAT_BASIC_WAVES_PER_SIMD
+#define CRT_FLAT_BASIC_WAVES_PER_SIMD 6
+#endif
+#ifndef CRT_FLAT_WAVES_PER_SIMD
+#define CRT_FLAT_WAVES_PER_SIMD 5
 #endif
 #ifndef CRT_TREE_WAVES_PER_SIMD
-#define CRT_TREE_WAVES_PER_SIMD CRT_FUSED_WAVES_PER_SIMD   // the same for the tree-walk variants
+#define CRT_TREE_WAVES_PER_SIMD 4
 #endif
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kPasses = 14;          // color3 albedo3 emission3 normal3 depth opacity
-// Pixels of one work item: 8 wide, 8 rows in flat mode (one sample of every pixel fills a wave:
-// lanes that finish together add to different LDS words) and 4 rows in the tree modes (half the
-// LDS per wave, which there buys a fourth resident block per CU next to the traversal stacks).
+// Pixels of one work item: 8 wide, 4 rows (3.5 KB of pass sums per wave and open item: six
+// workgroups of the flat kernel, four of the tree walks with their traversal stacks, fit a CU's LDS).
 constexpr int kTileW = 8;
-constexpr int tile_rows(int mode) { return mode == 2 ? 8 : 4; }
-constexpr int waves_per_simd(int mode) { return mode == 2 ? CRT_FUSED_WAVES_PER_SIMD : CRT_TREE_WAVES_PER_SIMD; }
+#ifndef CRT_FLAT_TILE_ROWS
+#define CRT_FLAT_TILE_ROWS 4
+#endif
+constexpr int tile_rows(int mode) { return mode == 2 ? CRT_FLAT_TILE_ROWS : 4; }
+constexpr int waves_per_simd(int mode, int feat) { return mode != 2 ? CRT_TREE_WAVES_PER_SIMD : (feat == 0 ? CRT_FLAT_BASIC_WAVES_PER_SIMD : CRT_FLAT_WAVES_PER_SIMD); }
 
 // How a kernel reaches the scene geometry
 enum : int {
@@ -143,7 +153,7 @@ struct WorkItem {
 // item, while the last long paths of the previous item (`drain`) finish, so the wave stays
 // full across item boundaries; an item's tile sums go to HBM once its last path has ended.
 template <int MODE, int STACK, int GROUPS, int FAST, int FEAT = kFeatAll>
-__global__ __launch_bounds__(kBlock, waves_per_simd(MODE)) void render_fused(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fused(RenderArgs A) {
     constexpr int kTileH = tile_rows(MODE), kTilePixels = kTileW * kTileH;
     constexpr int kAccFloatsPerTile = kPasses * kTilePixels, kAccFloatsPerWave = 2 * kAccFloatsPerTile;
     extern __shared__ float4 smem[];
@@ -1145,6 +1155,8 @@ int kernel_mode(const crt_scene* sc) {
     }
 }
 
+int variant_features(const crt_scene* sc);
+
 template <int STACK, int FAST, int FEAT>
 int launch_tree_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     size_t lds = (size_t)kWaves * wave_lds_bytes(kModeTreeGlobal) + (size_t)(STACK + 8) * kBlock * sizeof(int);
@@ -1159,8 +1171,7 @@ int launch_tree_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
 }
 template <int STACK, int FAST>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
-    // the flat mode's feature bits say nothing about a tree walk
-    if ((sc->features & ~(kFeatSlotXf | kFeatWide)) == 0) return launch_tree_feat<STACK, FAST, kFeatBasic>(sc, A, grid, mode);
+    if (variant_features(sc) == kFeatBasic) return launch_tree_feat<STACK, FAST, kFeatBasic>(sc, A, grid, mode);
     return launch_tree_feat<STACK, FAST, kFeatAll>(sc, A, grid, mode);
 }
 
@@ -1169,12 +1180,22 @@ void launch_flat_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds)
     if (sc->dev.fast_rcp) hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 1, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
     else hipLaunchKernelGGL((render_fused<kModeFlat, 0, GROUPS, 0, FEAT>), grid, dim3(kBlock), lds, sc->stream, A);
 }
+// The feature set of the kernel variant a scene runs: the smallest compiled set that covers it.
+int variant_features(const crt_scene* sc) {
+    if (kernel_mode(sc) == kModeFlat) {
+        if ((sc->features & ~kFeatBasic) == 0) return kFeatBasic;
+        return (sc->features & kFeatPlainXf) ? kFeatAll : (kFeatAll & ~kFeatPlainXf);
+    }
+    // the flat mode's feature bits say nothing about a tree walk
+    return (sc->features & ~(kFeatSlotXf | kFeatWide)) == 0 ? kFeatBasic : kFeatAll;
+}
 template <int GROUPS>
 void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
-    // the variant compiled for the smallest feature set that covers the scene
-    if ((sc->features & ~kFeatBasic) == 0) launch_flat_feat<GROUPS, kFeatBasic>(sc, A, grid, lds);
-    else if ((sc->features & kFeatPlainXf) == 0) launch_flat_feat<GROUPS, kFeatAll & ~kFeatPlainXf>(sc, A, grid, lds);
-    else launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds);
+    switch (variant_features(sc)) {
+    case kFeatBasic: launch_flat_feat<GROUPS, kFeatBasic>(sc, A, grid, lds); break;
+    case kFeatAll & ~kFeatPlainXf: launch_flat_feat<GROUPS, kFeatAll & ~kFeatPlainXf>(sc, A, grid, lds); break;
+    default: launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds); break;
+    }
 }
 
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
@@ -1935,7 +1956,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
     sc->spill_entries = std::max(0, need - stack_entries);
-    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(CRT_FUSED_WAVES_PER_SIMD, CRT_TREE_WAVES_PER_SIMD), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
+    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), CRT_TREE_WAVES_PER_SIMD), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
         CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
     }
@@ -2196,7 +2217,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     CRT_HIP(hipMemsetAsync(S.counters, 0, 2 * sizeof(unsigned long long), sc->stream));
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
     const long long items = (long long)plan.ntiles * plan.chunks;
-    int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc)) / kWaves);   // 4 SIMDs per CU
+    int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc), variant_features(sc)) / kWaves);   // 4 SIMDs per CU
     if (sc->opt.blocks > 0) resident = std::min(sc->spill_threads / kBlock, sc->opt.blocks);
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
