@@ -138,6 +138,7 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
 constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
+constexpr int kParkWords = 3;                    // flat mode: per-lane path state kept in LDS
 static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
 constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave) * 4 + kCamWords * 4 / kWaves; }
 
@@ -165,7 +166,11 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     DevCamera* lds_cam = reinterpret_cast<DevCamera*>(coop_all + kWaves * kCoopWordsPerWave);
     int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords);
     float* entry_mem = reinterpret_cast<float*>(stack_mem + STACK * kBlock);      // tree modes: 4 slot codes + 4 box entry distances per lane
-    float4* lds_scene = reinterpret_cast<float4*>(entry_mem + (MODE == kModeFlat ? 0 : 8 * kBlock));
+    // Flat mode: the albedo a path shows in the albedo pass is found at its first hit and only added when
+    // the path ends (an exhausted path shows black, render.cuh:96-97); it waits in LDS, three words per
+    // lane, instead of three registers that would be live through every traversal in between.
+    float* park = entry_mem + threadIdx.x;
+    float4* lds_scene = reinterpret_cast<float4*>(entry_mem + (MODE == kModeFlat ? kParkWords * kBlock : 8 * kBlock));
     const DevScene& sc = A.sc;
     if (threadIdx.x == 0) *lds_cam = sc.cam;
 
@@ -235,7 +240,15 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     int pixoff = 0;                                               // buffer * 448 + pixel of the tile: where this lane's path adds its results
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
-    V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
+    V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);       // (pend_albedo: tree modes; flat mode keeps it in `park`)
+    auto set_pending_albedo = [&](V3 a) {
+        if constexpr (MODE == kModeFlat) { park[0] = a.x; park[kBlock] = a.y; park[2 * kBlock] = a.z; }
+        else pend_albedo = a;
+    };
+    auto pending_albedo = [&]() {
+        if constexpr (MODE == kModeFlat) return v3(park[0], park[kBlock], park[2 * kBlock]);
+        else return pend_albedo;
+    };
     int bounces = 0;
     Rng rng;
     rng.state = 0; rng.draws = 0;
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                         rng.init(pj * sc.width + pi, sample);
                         ray = camera_ray<FEAT>(*lds_cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
-                        pend_albedo = v3(0, 0, 0);
+                        if constexpr (MODE != kModeFlat) pend_albedo = v3(0, 0, 0);   // (first read after a bounce-0 hit has set it)
                         bounces = 0;
                         alive = true;
                         if constexpr (MODE != kModeFlat) { ts.begin(INFINITY, sc.root_entry); walking = true; }
@@ -308,8 +321,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             else tree_run<FAST, FEAT>(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
             ready = alive && !walking;
         }
+        rays += (unsigned int)__builtin_popcountll(__ballot(ready));   // one count per wave, in a scalar register
         if (ready) {
-            rays++;
             CRT_PROF(kProfTrace);
             if constexpr (MODE == kModeFlat) {
                 CRT_CLOCK(clk, kSecBox, ray.o.y);
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                 Ray next;
                 if (scatter_with<FEAT>(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
-                        pend_albedo = attenuation;
+                        set_pending_albedo(attenuation);
                         V3 n = sf.unit_normal;
                         if (!sf.has_unit) n = unit(sf.normal);
                         acc_add3<kTilePixels>(acc, 9, pixoff, n);
@@ -353,9 +366,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     V3 emitted = emit<FEAT>(sc, sf);
                     V3 c = throughput * emitted;
                     acc_add3<kTilePixels>(acc, 0, pixoff, c);
-                    V3 alb = pend_albedo;
+                    V3 alb = emitted;
+                    if (bounces != 0) alb = pending_albedo();
                     if (bounces == 0) {
-                        alb = emitted;
                         V3 n = sf.unit_normal;
                         if (!sf.has_unit) n = unit(sf.normal);
                         acc_add3<kTilePixels>(acc, 6, pixoff, emitted);
@@ -369,9 +382,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment<FEAT>(sc, ray.d);
                 acc_add3<kTilePixels>(acc, 0, pixoff, c);
-                V3 alb = pend_albedo;
+                V3 alb = c;
+                if (bounces != 0) alb = pending_albedo();
                 if (bounces == 0) {
-                    alb = c;
                     atomicAdd(&acc[12 * kTilePixels + pixoff], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
                 }
                 acc_add3<kTilePixels>(acc, 3, pixoff, alb);
@@ -383,10 +396,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     clk.flush();
 
     // one ray-count atomic per wave
-    unsigned int total = rays;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (lane == 0) atomicAdd(A.ray_counter, (unsigned long long)total);
+    if (lane == 0) atomicAdd(A.ray_counter, (unsigned long long)rays);
 }
 
 struct ResolveArgs {
@@ -1201,7 +1211,7 @@ void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
 int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
     const int mode = kernel_mode(sc);
     if (mode == kModeFlat) {
-        size_t lds = (size_t)kWaves * wave_lds_bytes(kModeFlat) + (size_t)sc->lds_flat_bytes;
+        size_t lds = (size_t)kWaves * wave_lds_bytes(kModeFlat) + (size_t)kParkWords * kBlock * sizeof(float) + (size_t)sc->lds_flat_bytes;
         switch (sc->flat.groups) {
         case 0: launch_flat<0>(sc, A, grid, lds); break;
         case 1: launch_flat<1>(sc, A, grid, lds); break;
