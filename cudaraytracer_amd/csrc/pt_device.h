@@ -301,6 +301,28 @@ __device__ __forceinline__ float reciprocal(float x, int fast) {
     }
     return 1.0f / x;
 }
+// a / s.  With `fast`: through the exact reciprocal r of s and one correction step (q0 = a*r, the
+// remainder a - s*q0 comes out of one fma exactly, q = q0 + remainder*r): the correctly rounded
+// quotient whenever r is the correctly rounded reciprocal and nothing underflows (Markstein), five
+// instructions after the shared reciprocal instead of the eleven of the general division sequence;
+// sampled against the IEEE quotient in tools/ubench/rcp_exhaustive.hip.  A zero numerator keeps its
+// sign through q0.  Same condition on the scene as reciprocal().
+__device__ __forceinline__ float quotient(float a, float s, float r) {
+    const float q0 = a * r;
+    const float rem = __builtin_fmaf(-s, q0, a);
+    const float q = __builtin_fmaf(rem, r, q0);
+    return a == 0.0f ? q0 : q;
+}
+template <int FAST>
+__device__ __forceinline__ V3 divide(V3 v, float s) {
+    if (FAST) {
+        const float r = reciprocal(s, 1);
+        return v3(quotient(v.x, s, r), quotient(v.y, s, r), quotient(v.z, s, r));
+    }
+    return v / s;
+}
+template <int FAST>
+__device__ __forceinline__ V3 unit_vector(V3 a) { return divide<FAST>(a, length(a)); }   // vec3.cuh unit(): v / length
 
 __device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3& oo, V3& od) {   // hittable.cuh:429-430
     V3 anchor = v3(xf[9], xf[10], xf[11]), trans = v3(xf[12], xf[13], xf[14]);
@@ -353,6 +375,7 @@ __device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 point, V3 e1, V3 e2, flo
 }
 
 // hit_sphere, hittable.cuh:272-290 (acceptance part).  Interval test is exclusive.
+template <int FAST>
 __device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd, float radius, float tmin, float tmax, float& t) {
     V3 center = c0 + cd * time;
     V3 oc = o - center;
@@ -362,9 +385,10 @@ __device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd
     float disc = h * h - a * c;
     if (disc < 0.0f) return false;
     float sq = sqrtf(disc);
-    float root = (-h - sq) / a;
+    const float ra = FAST ? reciprocal(a, 1) : 0.0f;
+    float root = FAST ? quotient(-h - sq, a, ra) : (-h - sq) / a;
     if (!(tmin < root && root < tmax)) {
-        root = (-h + sq) / a;
+        root = FAST ? quotient(-h + sq, a, ra) : (-h + sq) / a;
         if (!(tmin < root && root < tmax)) return false;
     }
     t = root;
@@ -436,7 +460,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
         // the root the reference would take does not depend on the interval's upper end: the
         // near root if it is beyond tmin, else the far one (hittable.cuh:283-289)
         float t = 0.0f;
-        const bool ok = sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, INFINITY, t);
+        const bool ok = sphere_test<FAST>(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, INFINITY, t);
         consider(ts.best, ts.best_tri, ok, t, rank, false, 0.0f, 0.0f);
     }
     if (ts.best.obj != before) ts.best_obj = obj;
@@ -855,7 +879,8 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             float c = length_squared(oc) - q0.w * q0.w;
             float disc = h * h - a * c;
             float sq = sqrtf(disc);
-            float r1 = (-h - sq) / a, r2 = (-h + sq) / a;
+            const float ra = FAST ? reciprocal(a, 1) : 0.0f;
+            float r1 = FAST ? quotient(-h - sq, a, ra) : (-h - sq) / a, r2 = FAST ? quotient(-h + sq, a, ra) : (-h + sq) / a;
             float root = (tmin < r1 && r1 < tmax) ? r1 : r2;
             bool ok = !(disc < 0.0f) && (tmin < root && root < tmax);
             consider(best, best_tri, ok, root, rank_a, false, 0.0f, 0.0f);
@@ -867,7 +892,9 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
 // ------------------------------------------------------------------ textures ------------
 // Software tex2D: wrap addressing, bilinear, normalised coordinates, 8-bit -> [0,1]
 // (sampler state at texture.cuh:212-217).
-__device__ __forceinline__ int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+// i modulo n for -n <= i < 2n.  tex2d() only asks for floor(x) and floor(x) + 1 with x in
+// [-0.5, n - 0.5], i.e. -1 .. n: one conditional add and subtract instead of an integer division.
+__device__ __forceinline__ int wrapi(int i, int n) { i = i < 0 ? i + n : i; return i >= n ? i - n : i; }
 __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, float out[4]) {
     float x = (u - floorf(u)) * (float)img.width - 0.5f;
     float y = (v - floorf(v)) * (float)img.height - 0.5f;
@@ -940,7 +967,7 @@ struct Surface {
 // ALWAYS_UV = false: the (u, v) of a sphere, an acosf and an atan2f, are only computed for objects
 // on which something reads them (flag bit 1 of the shading record: an image texture under the
 // material or a normal map); the render never looks at them otherwise.
-template <bool ALWAYS_UV, int FEAT = kFeatAll>
+template <bool ALWAYS_UV, int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
     const float4* pq = sc.prims + h.obj * kPrimQuads;
     const float4* sq = sc.shade + h.obj * kShadeQuads;
@@ -970,7 +997,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
             c0 = cq[0]; c1 = cq[1]; c2 = cq[2]; c3 = cq[3];
         }
         V3 n;
-        if (flags & 1) n = unit(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(c0.x, c0.y, c0.z));
+        if (flags & 1) n = unit_vector<FAST>(w * v3(s0.x, s0.y, s0.z) + h.bu * v3(s1.x, s1.y, s1.z) + h.bv * v3(c0.x, c0.y, c0.z));
         else n = v3(s0.x, s0.y, s0.z);
         s.front = dot(d, n) < 0.0f;
         s.normal = s.front ? n : -n;
@@ -992,7 +1019,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         V3 c0 = v3(q0.x, q0.y, q0.z), cd = v3(q1.x, q1.y, q1.z);
         float radius = q0.w;
         V3 center = c0 + cd * r.time;
-        V3 outward = (p - center) / radius;
+        V3 outward = divide<FAST>(p - center, radius);
         s.front = dot(d, outward) < 0.0f;
         s.normal = s.front ? outward : -outward;
         s.u = 0.0f; s.v = 0.0f;
@@ -1037,7 +1064,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         V3 wn = v3(tangent.x * pixel.x + bitangent.x * pixel.y + s.normal.x * pixel.z,
                    tangent.y * pixel.x + bitangent.y * pixel.y + s.normal.y * pixel.z,
                    tangent.z * pixel.x + bitangent.z * pixel.y + s.normal.z * pixel.z);
-        s.normal = unit(wn);
+        s.normal = unit_vector<FAST>(wn);
     }
     return s;
 }
@@ -1085,6 +1112,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+template <int FAST = 0>
 __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng& rng, uint32_t* pub, float* res, int lane) {
     V3 out = v3(0.0f, 0.0f, 0.0f);
     bool pending = false;
@@ -1131,7 +1159,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
         wave_lds_sync();                                    // the next round overwrites pub and res
         mask = __ballot(pending);
     }
-    if (need && !in_sphere) out = unit(out);
+    if (need && !in_sphere) out = unit_vector<FAST>(out);
     return out;
 }
 
@@ -1139,7 +1167,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
 // coop_sphere_sample): `rv` is the random unit vector for a lambertian surface, the in-sphere
 // vector for a metal.  Returns false when the material does not scatter (light, or a metal
 // bounce that points into the surface).
-template <int FEAT = kFeatAll>
+template <int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, const Surface& s, float4 m0, V3 rv, Rng& rng, V3& attenuation, Ray& out) {
     int type = __float_as_int(m0.x);
     out.time = in.time;
@@ -1154,7 +1182,7 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
     if (!(FEAT & kFeatMaterials)) return false;                // neither metal nor glass in the scene: a light
     if (type == 1) {                                           // metal :311-322
         float4 m1 = sc.mats[s.mat * 2 + 1];
-        V3 unit_dir = unit(in.d);
+        V3 unit_dir = unit_vector<FAST>(in.d);
         V3 reflected = reflect(unit_dir, s.normal);
         out.o = s.p;
         out.d = reflected + m0.z * rv;
@@ -1167,7 +1195,7 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
         attenuation = v3(1.0f, 1.0f, 1.0f);
         float ior = m0.w;
         float ratio = s.front ? (1.0f / ior) : ior;
-        V3 unit_dir = unit(in.d);
+        V3 unit_dir = unit_vector<FAST>(in.d);
         float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool do_reflect = ratio * sin_theta > 1.0f;
@@ -1192,11 +1220,11 @@ __device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
     return v3(0.0f, 0.0f, 0.0f);
 }
 // Environment lookup on a miss (render.cuh:77-82)
-template <int FEAT = kFeatAll>
+template <int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ V3 environment(const DevScene& sc, V3 dir) {
     float4 t0 = sc.texs[sc.background_index * 2];
     if (!(FEAT & kFeatEnvTexture) || __float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
-    V3 p = unit(dir);
+    V3 p = unit_vector<FAST>(dir);
     float theta = acosf(-p.y);
     float phi = atan2f(-p.z, p.x) + kPi;
     float u = phi / (2 * kPi);

@@ -334,25 +334,25 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
                 if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
-                sf = make_surface<false, FEAT>(sc, ray, h);
+                sf = make_surface<false, FEAT, FAST>(sc, ray, h);
                 m0 = sc.mats[sf.mat * 2];
                 mat_type = __float_as_int(m0.x);
             }
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
         CRT_CLOCK(clk, kSecSample, sf.p.x);
-        const V3 rv = coop_sphere_sample(mat_type == 0 || ((FEAT & kFeatMaterials) && mat_type == 1), (FEAT & kFeatMaterials) && mat_type == 1, rng, coop_pub, coop_res, lane);
+        const V3 rv = coop_sphere_sample<FAST>(mat_type == 0 || ((FEAT & kFeatMaterials) && mat_type == 1), (FEAT & kFeatMaterials) && mat_type == 1, rng, coop_pub, coop_res, lane);
         V3 rv_dep = rv;
         CRT_CLOCK(clk, kSecScatter, rv_dep.x);
         if (ready) {
             if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
-                if (scatter_with<FEAT>(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
+                if (scatter_with<FEAT, FAST>(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         set_pending_albedo(attenuation);
                         V3 n = sf.unit_normal;
-                        if (!sf.has_unit) n = unit(sf.normal);
+                        if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
                         acc_add3<kTilePixels>(acc, 9, pixoff, n);
                         acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
                         acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     if (bounces != 0) alb = pending_albedo();
                     if (bounces == 0) {
                         V3 n = sf.unit_normal;
-                        if (!sf.has_unit) n = unit(sf.normal);
+                        if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
                         acc_add3<kTilePixels>(acc, 6, pixoff, emitted);
                         acc_add3<kTilePixels>(acc, 9, pixoff, n);
                         acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
-                V3 c = throughput * environment<FEAT>(sc, ray.d);
+                V3 c = throughput * environment<FEAT, FAST>(sc, ray.d);
                 acc_add3<kTilePixels>(acc, 0, pixoff, c);
                 V3 alb = c;
                 if (bounces != 0) alb = pending_albedo();
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs A) {
         h.t = 0.0f; h.obj = obj; h.bu = 0.0f; h.bv = 0.0f;
         bool ok;
         if (type == 2) ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, tmax, 0, h.t, h.bu, h.bv);
-        else ok = sphere_test(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, h.t);
+        else ok = sphere_test<0>(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, tmax, h.t);
         if (!ok) return;
         const Surface sf = make_surface<true>(sc, r, h);
         out[0] = 1.0f; out[1] = h.t; out[2] = sf.u; out[3] = sf.v; out[4] = sf.front ? 1.0f : 0.0f;
@@ -1225,7 +1225,8 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
 }
 
 // True when every divisor the kernels invert on the path (triangle determinants that pass the
-// 1e-8 test, ray direction components beyond 1e-12) is guaranteed to lie in [2^-100, 2^100],
+// 1e-8 test, ray direction components beyond 1e-12, and the divisors of quotient(): squared and
+// plain lengths of directions and normals, sphere radii) is guaranteed to lie in [2^-100, 2^100],
 // where the Newton-refined hardware reciprocal equals the IEEE quotient bit for bit.  The lower
 // ends are the path's own thresholds; the upper ends follow from the scene: a direction is a
 // camera ray (bounded by the view plane), normal + unit vector, a reflection + fuzz * unit-ball
@@ -1258,9 +1259,11 @@ bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
         if (o.type == CRT_OBJ_TRI) {
             edges = std::max(edges, len(o.p1) * len(o.p2));
             if (o.normal_idx < 0 && !o.shade_smooth) normal = std::max(normal, len(o.n0) * rot_fwd);
-        } else if (o.normal_idx < 0) {
+        } else {
+            // the radius divides (p - centre), |d|^2 divides the roots: both through quotient()
             const double radius = std::fabs((double)o.p2[0]);
-            if (!(radius > 0.0)) return false;
+            if (!(radius > 0x1p-80 && radius < 0x1p80)) return false;
+            if (o.normal_idx >= 0) continue;
             const double reach = len(o.p0) + len(o.p1) + radius + len(o.anchor) + len(o.translation);
             normal = std::max(normal, (1.0 + 4e-6 * reach / radius) * rot_fwd);
         }
@@ -1280,7 +1283,10 @@ bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
         }
     }
     const double dir_object = dir * rot;
-    return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p90 && edges * dir_object < 0x1p99;
+    // |d|^2 (sphere roots) and |d| (unit vectors) are divisors too: 3 dir^2 must stay below 2^100.  (Their lower ends
+    // are not proven but practically certain: a scattered direction is normal + unit vector with a component
+    // beyond 1e-8, a reflection plus a bounded fuzz vector, a refraction, or a camera ray.)
+    return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p48 && edges * dir_object < 0x1p99;
 }
 
 // Leaf slots in the order the reference's traversal visits them when every box is hit
