@@ -114,8 +114,10 @@ enum : int {
     kFeatMaterials = 1 << 5,    // metal or dielectric materials
     kFeatEnvTexture = 1 << 6,   // the environment is not one colour
     kFeatCamera = 1 << 7,       // orthographic camera, defocus blur, moving spheres (ray time)
-    kFeatAll = 0xff,
-    kFeatBasic = 0              // flat triangles under diffuse materials and lights of one colour, pinhole camera
+    kFeatXform = 1 << 8,        // objects under a transform (rotate / translate wrappers)
+    kFeatAll = 0x1ff,
+    kFeatBasic = 0,             // untransformed flat triangles under diffuse materials and lights of one colour, pinhole camera
+    kFeatBasicXform = kFeatXform   // the same with transformed objects (rotated boxes)
 };
 
 struct DevImage {
@@ -445,12 +447,18 @@ struct TreeState {
     __device__ __forceinline__ Hit result() const { Hit h = best; h.obj = best_obj; return h; }
 };
 
+// Keeps a loaded record whole: without it the compiler moves the loads of fields that are only read
+// under later branches (a triangle's first vertex after the determinant test, its rank after the
+// interval test) down into those branches, and a primitive test then waits for memory three times.
+__device__ __forceinline__ void keep_loaded(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+
 template <int FAST, int FEAT = kFeatAll, class Mem>
 __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, float tmin, TreeState& ts) {
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
+    keep_loaded(q0); keep_loaded(q1); keep_loaded(q2);
     const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
     V3 o = r.o, d = r.d;
-    if (xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(S.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
+    if ((FEAT & kFeatXform) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(S.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
     const int before = ts.best.obj;
     if (!(FEAT & kFeatSphere) || type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
@@ -973,7 +981,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     const float4* sq = sc.shade + h.obj * kShadeQuads;
     float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
     float4 s0 = sq[0], s1 = sq[1];
-    int xf = __float_as_int(q2.y), type = __float_as_int(q2.z);
+    const int xf = (FEAT & kFeatXform) ? __float_as_int(q2.y) : -1, type = __float_as_int(q2.z);
     const int packed = __float_as_int(s1.w);
     // without kFeatShading every object is a flat triangle without a normal map (flag bit 2) or a sphere
     const int flags = (FEAT & kFeatShading) ? (packed & 7) : 4;

@@ -55,7 +55,7 @@ constexpr int kTileW = 8;
 #define CRT_FLAT_TILE_ROWS 4
 #endif
 constexpr int tile_rows(int mode) { return mode == 2 ? CRT_FLAT_TILE_ROWS : 4; }
-constexpr int waves_per_simd(int mode, int feat) { return mode != 2 ? CRT_TREE_WAVES_PER_SIMD : (feat == 0 ? CRT_FLAT_BASIC_WAVES_PER_SIMD : CRT_FLAT_WAVES_PER_SIMD); }
+constexpr int waves_per_simd(int mode, int feat) { return mode != 2 ? CRT_TREE_WAVES_PER_SIMD : (feat == kFeatBasicXform ? CRT_FLAT_BASIC_WAVES_PER_SIMD : CRT_FLAT_WAVES_PER_SIMD); }
 
 // How a kernel reaches the scene geometry
 enum : int {
@@ -1193,7 +1193,7 @@ void launch_flat_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds)
 // The feature set of the kernel variant a scene runs: the smallest compiled set that covers it.
 int variant_features(const crt_scene* sc) {
     if (kernel_mode(sc) == kModeFlat) {
-        if ((sc->features & ~kFeatBasic) == 0) return kFeatBasic;
+        if ((sc->features & ~kFeatBasicXform) == 0) return kFeatBasicXform;
         return (sc->features & kFeatPlainXf) ? kFeatAll : (kFeatAll & ~kFeatPlainXf);
     }
     // the flat mode's feature bits say nothing about a tree walk
@@ -1202,7 +1202,7 @@ int variant_features(const crt_scene* sc) {
 template <int GROUPS>
 void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
     switch (variant_features(sc)) {
-    case kFeatBasic: launch_flat_feat<GROUPS, kFeatBasic>(sc, A, grid, lds); break;
+    case kFeatBasicXform: launch_flat_feat<GROUPS, kFeatBasicXform>(sc, A, grid, lds); break;
     case kFeatAll & ~kFeatPlainXf: launch_flat_feat<GROUPS, kFeatAll & ~kFeatPlainXf>(sc, A, grid, lds); break;
     default: launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds); break;
     }
@@ -1671,6 +1671,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         c[8] = o.uv2[0]; c[9] = o.uv2[1]; c[10] = o.tangent[0]; c[11] = o.tangent[1];
         c[12] = o.tangent[2]; c[13] = o.bitangent[0]; c[14] = o.bitangent[1]; c[15] = o.bitangent[2];
     }
+    const bool xforms_used = !xforms.empty();
     if (xforms.empty()) xforms.assign(kXformFloats, 0.0f);
     std::vector<float> mat_rec((size_t)std::max(1, d->material_count) * 8, 0.0f);
     for (int i = 0; i < d->material_count; i++) {
@@ -2021,6 +2022,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     {
         int feat = 0;
         if (has_plain_xf) feat |= kFeatPlainXf;
+        if (xforms_used) feat |= kFeatXform;
         if (flat_slot_xf || !can_flat) feat |= kFeatSlotXf;
         if (flat_slot_count > 32) feat |= kFeatWide;
         for (int i = 0; i < d->object_count; i++) {
@@ -2118,7 +2120,7 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%02x slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
+    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%03x slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
                                 sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
                                 sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
                                 sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");

@@ -51,10 +51,10 @@ def test_cornell_runs_the_specialised_variant(crt):
     sc.upload()
     text = sc.describe()
     sc.close()
-    assert "mode=flat" in text and "features=0x00" in text and "cuboids=3" in text, text
+    assert "mode=flat" in text and "features=0x100" in text and "cuboids=3" in text, text
     sc = crt.load_scene(scene_path("cornell_box.yaml"))
     sc.set_options(general_kernel=1, flat_cuboids=2)
     sc.upload()
     text = sc.describe()
     sc.close()
-    assert "features=0xff" in text and "cuboids=0" in text, text
+    assert "features=0x1ff" in text and "cuboids=0" in text, text
