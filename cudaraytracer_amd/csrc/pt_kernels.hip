@@ -2225,8 +2225,17 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     A.partial = S.partial;
     A.stack_spill = sc->stack_spill;
     A.spill_threads = sc->spill_threads;
-    A.prim_batch = sc->opt.prim_batch > 0 ? sc->opt.prim_batch : 8;
-    A.ready_percent = sc->opt.ready_percent > 0 ? sc->opt.ready_percent : 65;
+    // Scheduling of the tree walk (measured sweeps, profiles/r2_e_sweep*).  A hierarchy that fits an XCD's 4 MB L2
+    // runs best with primitive tests in batches of 8 lanes and shading once 65 % of the wave's walks have ended (the
+    // 976-triangle mesh: 10.3 ms; 10.5-11.7 elsewhere in the sweep).  One that does not fit waits on memory in every
+    // step and shades earlier, at 45-50 %; its best batch depends on how long a wave stays on one pixel tile: with many
+    // samples per work item the lanes' rays are close to each other, reach leaves together and fill batches of 16
+    // (1 M triangles at 128 spp: 390 ms against 403 with the small-scene setting), with few samples per item
+    // primitives are best tested as soon as two lanes hold some (the same scene at 8 spp: 30.7 ms against 32.5).
+    const bool beyond_l2 = (size_t)sc->dev.node_count * kNodeStrideGlobal * 16 > ((size_t)4 << 20);
+    const bool long_items = plan.chunk_size >= 32;
+    A.prim_batch = sc->opt.prim_batch > 0 ? sc->opt.prim_batch : (beyond_l2 ? (long_items ? 16 : 2) : 8);
+    A.ready_percent = sc->opt.ready_percent > 0 ? sc->opt.ready_percent : (beyond_l2 ? 45 : 65);
     A.band_tiles = plan.band_tiles;
     A.band_index = bands.index;
     A.band_count = bands.count;

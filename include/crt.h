@@ -190,8 +190,8 @@ typedef struct crt_scene_options {
     int32_t ieee_division;    /* 1: never use the Newton-refined reciprocal                    */
     int32_t work_items;       /* work items (pixel tile x sample chunk) a frame is cut into; 0 = 65536 */
     int32_t blocks;           /* workgroups of the persistent render kernel; 0 = fill the GPU  */
-    int32_t ready_percent;    /* tree walk: shade once this share of a wave's rays is done; 0 = 65 */
-    int32_t prim_batch;       /* tree walk: lanes with leaf candidates that start a test round; 0 = 8 */
+    int32_t ready_percent;    /* tree walk: shade once this share of a wave's rays is done; 0 = 65 (45 for hierarchies beyond 4 MB) */
+    int32_t prim_batch;       /* tree walk: lanes with leaf candidates that start a test round; 0 = 8 (2 or 16 for hierarchies beyond 4 MB) */
     int32_t deterministic;    /* 1: one sample per chunk, so every pixel sum is added in sample order and
                                  a render is bit-reproducible from run to run (costs 56 B of scratch per
                                  pixel AND sample instead of per pixel and chunk; a call may then render
