@@ -18,14 +18,16 @@
 //   * Objects whose transform is the identity with zero anchor and translation skip the
 //     two 3x3 products: (o - 0 - 0) + 0 and I*v are exact, so results do not change.
 //   * All float expressions keep the reference's association order and the file is built
-//     with -ffp-contract=off: with the shared counter RNG a path is reproducible bit for
-//     bit on a CPU as long as it does not touch acosf/atan2f/sinf/cosf/powf.
+//     with -ffp-contract=off; acos/atan2/sin/cos are the plain-float evaluations of det_math.h
+//     and (1-cos)^5 is a multiplication chain: with the shared counter RNG every path is
+//     reproducible bit for bit on a CPU that evaluates the same expressions.
 #ifndef CRT_PT_DEVICE_H
 #define CRT_PT_DEVICE_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "det_math.h"
 #include "vecmath.h"
 
 namespace crt {
@@ -1032,15 +1034,17 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         s.normal = s.front ? outward : -outward;
         s.u = 0.0f; s.v = 0.0f;
         if (ALWAYS_UV || ((FEAT & kFeatShading) && (flags & 2))) {
-            float theta = acosf(-outward.y);                             // get_sphere_uv
-            float phi = atan2f(-outward.z, outward.x) + kPi;
+            float theta = crt_det::acos(-outward.y);                     // get_sphere_uv
+            float phi = crt_det::atan2(-outward.z, outward.x) + kPi;
             s.u = phi / (2 * kPi);
             s.v = theta / kPi;
         }
         if (normal_idx >= 0) {                                           // get_tangent_bitangent: centre at rec.t
             V3 local_p = p - (c0 + cd * h.t);
-            float ph = atan2f(-local_p.z, local_p.x) + kPi;
-            tangent = unit(v3(-radius * sinf(ph), 0.0f, radius * cosf(ph)));
+            float ph = crt_det::atan2(-local_p.z, local_p.x) + kPi;
+            float sin_ph, cos_ph;
+            crt_det::sincos(ph, sin_ph, cos_ph);
+            tangent = unit(v3(-radius * sin_ph, 0.0f, radius * cos_ph));
             bitangent = unit(cross(s.normal, tangent));
         }
     }
@@ -1233,8 +1237,8 @@ __device__ __forceinline__ V3 environment(const DevScene& sc, V3 dir) {
     float4 t0 = sc.texs[sc.background_index * 2];
     if (!(FEAT & kFeatEnvTexture) || __float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
     V3 p = unit_vector<FAST>(dir);
-    float theta = acosf(-p.y);
-    float phi = atan2f(-p.z, p.x) + kPi;
+    float theta = crt_det::acos(-p.y);
+    float phi = crt_det::atan2(-p.z, p.x) + kPi;
     float u = phi / (2 * kPi);
     float v = theta / kPi;
     return texture_value(sc, sc.background_index, u, v, p);

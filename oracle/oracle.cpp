@@ -34,6 +34,7 @@
 #endif
 
 #include "../include/crt.h"
+#include "../cudaraytracer_amd/csrc/det_math.h"   // plain-float acos/atan2/sin/cos shared with the kernels (oracle_set_det_math)
 
 namespace {
 
@@ -41,6 +42,13 @@ const float k_pi = 3.1415926535897932385f;                       // utility.cuh:
 const float k_inf = std::numeric_limits<float>::infinity();      // utility.cuh:31-33
 
 bool g_pow5_mulchain = false;   // see oracle_set_pow5_mulchain()
+bool g_det_math = false;        // see oracle_set_det_math()
+inline float o_acos(float x) { return g_det_math ? crt_det::acos(x) : acosf(x); }
+inline float o_atan2(float y, float x) { return g_det_math ? crt_det::atan2(y, x) : atan2f(y, x); }
+inline void o_sincos(float x, float& s, float& c) {
+    if (g_det_math) { crt_det::sincos(x, s, c); return; }
+    s = sinf(x); c = cosf(x);
+}
 
 // ---------------------------------------------------------------- vec3.cuh:19-483 ------
 struct vec3 {
@@ -287,16 +295,18 @@ bool hit_sphere(const ray& r, interval ray_t, hit_record& rec, const crt_object&
     vec3 outward_normal = (rec.p - current_center) / radius;
     rec.set_face_normal(r, outward_normal);
     {                                                               // get_sphere_uv :179-184
-        float theta = acosf(-outward_normal.y());
-        float phi = atan2f(-outward_normal.z(), outward_normal.x()) + k_pi;
+        float theta = o_acos(-outward_normal.y());
+        float phi = o_atan2(-outward_normal.z(), outward_normal.x()) + k_pi;
         rec.u = phi / (2 * k_pi);
         rec.v = theta / k_pi;
     }
     rec.mat_idx = o.mat_idx;
     {                                                               // get_tangent_bitangent :191-197
         vec3 local_p = rec.p - (c0 + cd * rec.t);                   // center.at(rec.t) -- t, not time
-        float phi = atan2f(-local_p.z(), local_p.x()) + k_pi;
-        rec.tangent = unit_vector(vec3(-radius * sinf(phi), 0, radius * cosf(phi)));
+        float phi = o_atan2(-local_p.z(), local_p.x()) + k_pi;
+        float sin_phi, cos_phi;
+        o_sincos(phi, sin_phi, cos_phi);
+        rec.tangent = unit_vector(vec3(-radius * sin_phi, 0, radius * cos_phi));
         rec.bitangent = unit_vector(cross(rec.normal, rec.tangent));
     }
     return true;
@@ -534,8 +544,8 @@ void get_ray_info(const crt_scene_desc* sc, const ray& r, rng_state& rs, ray_inf
             }
         } else {
             vec3 p = unit_vector(cur_ray.dir);
-            float theta = acosf(-p.y());
-            float phi = atan2f(-p.z(), p.x()) + k_pi;
+            float theta = o_acos(-p.y());
+            float phi = o_atan2(-p.z(), p.x()) + k_pi;
             float u = phi / (2 * k_pi);
             float v = theta / k_pi;
             vec3 c = texture_value(sc, sc->background_index, u, v, p);
@@ -686,6 +696,14 @@ void free_nodes(build_node* n) {
 extern "C" {
 
 void oracle_set_pow5_mulchain(int on) { g_pow5_mulchain = on != 0; }
+// 1: acos/atan2/sin/cos through the plain-float evaluations the kernels use (bit-exact comparisons of
+// textured spheres and environment images); 0 (default): the C library's, like the reference's calls.
+void oracle_set_det_math(int on) { g_det_math = on != 0; }
+// the four functions themselves, for accuracy tests against the C library in double precision
+float oracle_det_acos(float x) { return crt_det::acos(x); }
+float oracle_det_atan2(float y, float x) { return crt_det::atan2(y, x); }
+float oracle_det_sin(float x) { float s, c; crt_det::sincos(x, s, c); return s; }
+float oracle_det_cos(float x) { float s, c; crt_det::sincos(x, s, c); return c; }
 
 // render() over the whole image; buffers are host arrays in the reference layout and are
 // read-modified-written exactly like render_kernel does.  stats: rays, node_pops, box_tests,

@@ -30,6 +30,13 @@ def load():
     lib.oracle_camera_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.oracle_set_pow5_mulchain.restype = None
     lib.oracle_set_pow5_mulchain.argtypes = [C.c_int]
+    lib.oracle_set_det_math.restype = None
+    lib.oracle_set_det_math.argtypes = [C.c_int]
+    for name in ("oracle_det_acos", "oracle_det_sin", "oracle_det_cos"):
+        getattr(lib, name).restype = C.c_float
+        getattr(lib, name).argtypes = [C.c_float]
+    lib.oracle_det_atan2.restype = C.c_float
+    lib.oracle_det_atan2.argtypes = [C.c_float, C.c_float]
     lib.oracle_aabb_hit.restype = C.c_int
     lib.oracle_aabb_hit.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float]
     lib.oracle_object_hit.restype = C.c_int

@@ -4,10 +4,10 @@ passes and the ray count must be equal bit for bit, sample after sample (see the
 which only very large images can show, at the comparison below).  Wrappers are nested at
 random too, which includes the combinations whose boxes do not contain their geometry.
 
-Image textures and normal maps sit on triangles only.  Left out on purpose: image textures and
-normal maps on spheres and environment images, whose
-texture coordinates go through acosf/atan2f (device and host libm differ in the last bit there;
-those have tolerance tests of their own)."""
+Image textures and normal maps sit on triangles and on spheres, and a quarter of the scenes have an
+environment image: the texture coordinates of spheres and of the environment go through acos /
+atan2 (and a sphere's tangent through sin / cos), which the kernels evaluate with the plain-float
+functions of det_math.h; the oracle is switched to the same evaluations for this test."""
 import os
 import random
 
@@ -76,6 +76,10 @@ def _object(rng, extent, wrappers, depth=0):
         if rng.random() < 0.2:
             mat += ", normal: {type: image, filename: rgb.png}"
     if kind < 0.45:
+        if rng.random() < 0.3:          # textured and normal-mapped spheres: (u, v) and the tangent through acos/atan2/sin/cos
+            mat = _material(rng, True)
+            if rng.random() < 0.4:
+                mat += ", normal: {type: image, filename: %s}" % rng.choice(["rgb.png", "grey.png"])
         c = _vec(rng, -extent, extent)
         moving = ", center2: %s" % _vec(rng, -extent, extent) if rng.random() < 0.25 else ""
         return "{type: sphere, center: %s%s, radius: %.4f, material: %s}" % (c, moving, rng.uniform(0.1, 0.9), mat)
@@ -104,7 +108,8 @@ def random_scene(seed, count):
     lines = ["camera: " + camera,
              "render: {width: %d, height: %d, samples: 3, max_bounces: %d}" % (_SCALE * rng.randint(9, 70), _SCALE * rng.randint(5, 45), rng.choice([1, 2, 3, 4, 6, 9, 30])),
              "environment:",
-             "  texture: {type: solid_color, color: %s}" % _vec(rng, 0.0, 1.0),
+             ("  texture: {type: image, filename: %s}" % rng.choice(["rgb.png", "rgba.png", "grey.png"])) if rng.random() < 0.25 else
+             ("  texture: {type: solid_color, color: %s}" % _vec(rng, 0.0, 1.0)),
              "objects:"]
     for _ in range(count):
         lines.append("  - " + _object(rng, extent, wrappers))
@@ -135,6 +140,7 @@ def test_random_scene_bit_exact_in_every_mode(crt, oracle, image_dir, seed, coun
     from cudaraytracer_amd import api
     text = random_scene(seed, count)
     oracle.oracle_set_pow5_mulchain(1)          # (1-cos)^5 as the device computes it: four multiplications
+    oracle.oracle_set_det_math(1)               # acos/atan2/sin/cos as the device computes them
     try:
         reference = None
         for mode in MODES:
@@ -176,4 +182,5 @@ def test_random_scene_bit_exact_in_every_mode(crt, oracle, image_dir, seed, coun
         assert reference is not None
     finally:
         oracle.oracle_set_pow5_mulchain(0)
+        oracle.oracle_set_det_math(0)
 

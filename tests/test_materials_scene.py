@@ -129,3 +129,39 @@ def test_gpu_vs_oracle_materials_with_hdr_environment(crt, oracle):
     # the sky is seen directly around the box and in the metal spheres: brighter than the black variant
     assert got["color"].mean() > images["materials.yaml"]["color"].mean() + 0.01
     assert np.array_equal(np.isnan(got["depth"]), np.isnan(images["materials.yaml"]["depth"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["materials.yaml", "materials_hdr.yaml"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gpu_bit_exact_with_shared_math(crt, oracle, name, mode):
+    """Every material, texture kind, the normal-mapped sphere and (materials_hdr) the environment image,
+    sample by sample and bit for bit: the kernels evaluate acos/atan2/sin/cos with the plain-float
+    functions of det_math.h and (1-cos)^5 as a multiplication chain, and the oracle is switched to the
+    same evaluations (its defaults are the C library's, like the reference's calls)."""
+    crt.set_image_loader(None)
+    sc = crt.load_scene(scene_path(name), base_dir=os.path.join(ROOT, "scenes"))
+    w, h = 400, 80
+    sc.set_render(w, h, samples=16)
+    sc.set_mode(mode)
+    buf = crt.create_buffer(sc)
+    dp = crt.lib().crt_host_scene_desc(sc._host)
+    ref = oracle_lib.new_passes(w, h)
+    from cudaraytracer_amd import api
+    oracle.oracle_set_pow5_mulchain(1)
+    oracle.oracle_set_det_math(1)
+    try:
+        for done in range(3):
+            crt.render(sc, buf, samples=1, samples_done=done)
+            got = buf.download()
+            _, stats = oracle_lib.render(oracle, dp, w, h, samples=1, samples_done=done, passes=ref)
+            assert api.last_ray_count == stats["rays"], (done, api.last_ray_count, stats["rays"])
+            for k in oracle_lib.PASSES:
+                a, b = got[k], ref[k]
+                same = (a == b) | (np.isnan(a) & np.isnan(b))
+                assert same.all(), f"{name} mode {mode}: pass {k} differs after sample {done + 1} in {int((~same).sum())} values, first at {np.flatnonzero(~same)[:6]}"
+    finally:
+        oracle.oracle_set_pow5_mulchain(0)
+        oracle.oracle_set_det_math(0)
+    buf.close()
+    sc.close()
