@@ -11,6 +11,7 @@ seed, count = int(sys.argv[1]), int(sys.argv[2])
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 o = oracle_lib.load()
 o.oracle_set_pow5_mulchain(1)
+o.oracle_set_det_math(1)
 text = f.random_scene(seed, count)
 import tempfile
 from PIL import Image
