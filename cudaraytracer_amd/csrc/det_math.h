@@ -45,26 +45,11 @@ CRT_DM float acos(float x) {
     return kHalfPiF - asin_core(x);
 }
 
-// atan(x) for x >= 0
-CRT_DM float atan_positive(float x) {
-    float base = 0.0f;
-    if (x > 2.414213562373095f) {            // tan(3 pi / 8)
-        base = kHalfPiF;
-        x = -1.0f / x;
-    } else if (x > 0.4142135623730950f) {    // tan(pi / 8)
-        base = kQuarterPiF;
-        x = (x - 1.0f) / (x + 1.0f);
-    }
-    const float z = x * x;
-    float p = 8.05374449538e-2f;
-    p = p * z - 1.38776856032e-1f;
-    p = p * z + 1.99777106478e-1f;
-    p = p * z - 3.33329491539e-1f;
-    return base + (p * z * x + x);
-}
-
 // atan2(y, x) in (-pi, pi].  Zeros: atan2(+-0, x > 0) = +-0, atan2(+-0, x < 0) = +-pi,
 // atan2(y, 0) = +-pi/2, atan2(0, 0) = 0; NaN in, NaN out.
+// The angle of (|x|, |y|) comes from ONE division: the octant decides which ratio is formed
+// (|y|/|x| below tan(pi/8), (|y|-|x|)/(|y|+|x|) up to tan(3 pi/8), -|x|/|y| above), then
+// atan(t) = t + t^3 P(t^2) on |t| <= tan(pi/8).
 CRT_DM float atan2(float y, float x) {
     if (x != x || y != y) return x + y;
     const bool y_negative = __builtin_signbit(y) != 0;
@@ -77,7 +62,19 @@ CRT_DM float atan2(float y, float x) {
         return y_negative ? -kPiF : kPiF;
     }
     const float ax = fabsf(x), ay = fabsf(y);
-    float a = atan_positive(ay / ax);        // angle of (|x|, |y|) in [0, pi/2]
+    float base = 0.0f, num = ay, den = ax;
+    if (ay > ax * 2.414213562373095f) {          // tan(3 pi / 8)
+        base = kHalfPiF; num = -ax; den = ay;
+    } else if (ay > ax * 0.4142135623730950f) {  // tan(pi / 8)
+        base = kQuarterPiF; num = ay - ax; den = ay + ax;
+    }
+    const float t = num / den;
+    const float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float a = base + (p * z * t + t);            // angle of (|x|, |y|) in [0, pi/2]
     if (x < 0.0f) a = kPiF - a;
     return y_negative ? -a : a;
 }
