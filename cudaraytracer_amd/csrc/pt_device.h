@@ -639,7 +639,7 @@ struct FlatView {                      // part of the kernel arguments
     const float4* boxes;               // [box_end[last]][2]: {minx,maxx,miny,maxy},{minz,maxz,0,0} of the slots outside cuboids,
                                        // then, from quad cuboid_quad0 on, the cuboid records: world group 5 quads each (flat_cuboid()),
                                        // rotated groups 4 quads each (flat_cuboid_shared())
-    const float4* slots;               // [slot_count][5]: see pack_slot() on the host
+    const float4* slots;               // [slot_count][5]: meta, transform, triangle A, triangle B (or a sphere), see traverse_flat()
     const int32_t* ent_obj;            // rank in the reference's visiting order -> object index
     const float* group_xf;             // [groups][24] transform of group 1.. (rinv, anchor, trans, rot)
     int32_t slot_count;
@@ -855,8 +855,11 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
         const int s = bit;                                     // the LDS copy is stored last slot first
         const float4* rec = L.slots + s * kSlotQuads;
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
-        const int meta = __float_as_int(q4.z), xf = __float_as_int(q4.w);
+        // record: {meta, transform, A.point.xy} {A.point.z, A.edge1} {A.edge2, B.point.x} {B.point.yz, B.edge1.xy} {B.edge1.z, B.edge2}
+        // (sphere: {meta, transform, centre.xy} {centre.z, radius, centre direction.xy} {centre direction.z, -, -, -}).
+        // Triangle B's part is only loaded after triangle A has been dealt with: eight registers fewer at the loop's peak.
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        const int meta = __float_as_int(q0.x), xf = __float_as_int(q0.y);
         const int rank_a = meta & 63, rank_b = (meta >> 6) & 63, group = (meta >> 15) & 3;
         const bool has_b = (meta >> 12) & 1, is_tri = ((meta >> 13) & 3) == 2;
         // the ray of the slot's group, component by component (selects in registers: written with
@@ -874,19 +877,21 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         }
         if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
         if (!(FEAT & kFeatSphere) || is_tri) {
-            // pair layout: {pxA,pxB,pyA,pyB} {pzA,pzB,e1xA,e1xB} {e1yA,e1yB,e1zA,e1zB} {e2xA,e2xB,e2yA,e2yB} {e2zA,e2zB,..}
-            TriEval A = tri_eval(o, d, v3(q0.x, q0.z, q1.x), v3(q1.z, q2.x, q2.z), v3(q3.x, q3.z, q4.x), tmin, tmax, FAST);
-            TriEval B = tri_eval(o, d, v3(q0.y, q0.w, q1.y), v3(q1.w, q2.y, q2.w), v3(q3.y, q3.w, q4.y), tmin, tmax, FAST);
+            const TriEval A = tri_eval(o, d, v3(q0.z, q0.w, q1.x), v3(q1.y, q1.z, q1.w), v3(q2.x, q2.y, q2.z), tmin, tmax, FAST);
             consider(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
+            float bx = q2.w;
+            asm volatile("" : "+v"(bx) : : "memory");              // keeps the two loads below behind triangle A
+            const float4 q3 = rec[3], q4 = rec[4];
+            const TriEval B = tri_eval(o, d, v3(bx, q3.x, q3.y), v3(q3.z, q3.w, q4.x), v3(q4.y, q4.z, q4.w), tmin, tmax, FAST);
             consider(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
         } else {
             // sphere slot: {c0.xyz, radius} {cd.xyz, 0}.  The root the reference would take does not
             // depend on the upper bound: the near root if it is beyond tmin, else the far one.
-            V3 center = v3(q0.x, q0.y, q0.z) + v3(q1.x, q1.y, q1.z) * r.time;
+            V3 center = v3(q0.z, q0.w, q1.x) + v3(q1.z, q1.w, q2.x) * r.time;
             V3 oc = o - center;
             float a = length_squared(d);
             float h = dot(oc, d);
-            float c = length_squared(oc) - q0.w * q0.w;
+            float c = length_squared(oc) - q1.y * q1.y;
             float disc = h * h - a * c;
             float sq = sqrtf(disc);
             const float ra = FAST ? reciprocal(a, 1) : 0.0f;

@@ -1915,14 +1915,14 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                 if (sl.type == CRT_OBJ_TRI) {
                     const float* fa[9] = {&A.p0[0], &A.p0[1], &A.p0[2], &A.p1[0], &A.p1[1], &A.p1[2], &A.p2[0], &A.p2[1], &A.p2[2]};
                     const float* fb[9] = {&B.p0[0], &B.p0[1], &B.p0[2], &B.p1[0], &B.p1[1], &B.p1[2], &B.p2[0], &B.p2[1], &B.p2[2]};
-                    for (int k = 0; k < 9; k++) { rec[2 * k] = *fa[k]; rec[2 * k + 1] = *fb[k]; }
+                    for (int k = 0; k < 9; k++) { rec[2 + k] = *fa[k]; rec[11 + k] = *fb[k]; }
                 } else {
-                    rec[0] = A.p0[0]; rec[1] = A.p0[1]; rec[2] = A.p0[2]; rec[3] = A.p2[0];
-                    rec[4] = A.p1[0]; rec[5] = A.p1[1]; rec[6] = A.p1[2];
+                    rec[2] = A.p0[0]; rec[3] = A.p0[1]; rec[4] = A.p0[2]; rec[5] = A.p2[0];
+                    rec[6] = A.p1[0]; rec[7] = A.p1[1]; rec[8] = A.p1[2];
                 }
                 const int32_t meta = sl.rank_a | (sl.rank_b << 6) | ((sl.has_b ? 1 : 0) << 12) | (sl.type << 13) | (sl.group << 15);
-                rec[18] = as_float(meta);
-                rec[19] = as_float(sl.xf);
+                rec[0] = as_float(meta);
+                rec[1] = as_float(sl.xf);
                 if (sl.xf >= 0) flat_slot_xf = true;
                 flat_slot_rec.insert(flat_slot_rec.end(), rec, rec + kSlotQuads * 4);
             }
