@@ -222,6 +222,15 @@ __device__ __forceinline__ Ray camera_ray(const DevCamera& cam, int i, int j, Rn
     return r;
 }
 
+// base[index] with the byte offset formed in 32 bits.  An `int` index is sign-extended and the address
+// computed in 64-bit vector arithmetic (two to four instructions per load); with an unsigned 32-bit byte
+// offset the load takes the table's address from scalar registers and the offset from one vector
+// register.  The host refuses a scene with a table of 4 GiB or more.
+template <class T>
+__device__ __forceinline__ const T* at32(const T* base, int index) {
+    return (const T*)((const char*)base + (uint32_t)index * (uint32_t)sizeof(T));
+}
+
 // ------------------------------------------------------------------ scene memory views --
 // Two views with the same interface: HBM (node-major records, served by L1/L2) and an LDS
 // copy (field-major, so that lanes on different nodes fall on different banks).
@@ -231,9 +240,13 @@ struct SceneGlobal {
     const float* xforms;
     int root_entry;        // stack entry of node 0
     int order_flip;        // 15: rays towards -z read a node's slot order backwards; 0: one order for every ray (reference-order walk)
-    __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[node * kNodeStrideGlobal + field]; }
-    __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[obj * kPrimQuads + q]; }
-    __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
+    __device__ __forceinline__ float4 node_field(int node, int field) const {
+        return *at32(nodes, node * kNodeStrideGlobal + field);
+    }
+    __device__ __forceinline__ float4 prim(int obj, int q) const {
+        return *at32(prims, obj * kPrimQuads + q);
+    }
+    __device__ __forceinline__ const float* xform(int x) const { return at32(xforms, x * kXformFloats); }
 };
 struct SceneLds {
     const float4* nodes;   // [7][node_count]
@@ -342,7 +355,7 @@ __device__ __forceinline__ void to_object_space(const float* xf, V3 o, V3 d, V3&
 constexpr int kXfIdentityRotation = 1 << 30;
 template <int FEAT = kFeatAll>
 __device__ __forceinline__ const float* xform_record(const float* xforms, int xf) {
-    return xforms + ((FEAT & kFeatPlainXf) ? (xf & ~kXfIdentityRotation) : xf) * kXformFloats;
+    return at32(xforms, ((FEAT & kFeatPlainXf) ? (xf & ~kXfIdentityRotation) : xf) * kXformFloats);
 }
 __device__ __forceinline__ void to_object_space(const float* X, bool plain, V3 o, V3 d, V3& oo, V3& od) {
     if (plain) {
@@ -921,8 +934,8 @@ __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, flo
     if (img.channels == 4) {
         // (the pointer comes out of memory, so the compiler cannot tell that it points to global memory)
         const uint32_t __attribute__((address_space(1)))* p = (const uint32_t __attribute__((address_space(1)))*)img.pixels;
-        const uint32_t a = p[(size_t)y0 * img.width + x0], b = p[(size_t)y0 * img.width + x1];     // r | g << 8 | b << 16 | a << 24
-        const uint32_t c = p[(size_t)y1 * img.width + x0], d = p[(size_t)y1 * img.width + x1];
+        const uint32_t a = p[(uint32_t)(y0 * img.width + x0)], b = p[(uint32_t)(y0 * img.width + x1)];     // r | g << 8 | b << 16 | a << 24
+        const uint32_t c = p[(uint32_t)(y1 * img.width + x0)], d = p[(uint32_t)(y1 * img.width + x1)];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float t00 = (float)((a >> (8 * k)) & 255u) * (1.0f / 255.0f), t10 = (float)((b >> (8 * k)) & 255u) * (1.0f / 255.0f);
@@ -931,8 +944,8 @@ __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, flo
         }
     } else {
         const uint8_t __attribute__((address_space(1)))* p = (const uint8_t __attribute__((address_space(1)))*)img.pixels;
-        float t00 = p[(size_t)y0 * img.width + x0] * (1.0f / 255.0f), t10 = p[(size_t)y0 * img.width + x1] * (1.0f / 255.0f);
-        float t01 = p[(size_t)y1 * img.width + x0] * (1.0f / 255.0f), t11 = p[(size_t)y1 * img.width + x1] * (1.0f / 255.0f);
+        float t00 = p[(uint32_t)(y0 * img.width + x0)] * (1.0f / 255.0f), t10 = p[(uint32_t)(y0 * img.width + x1)] * (1.0f / 255.0f);
+        float t01 = p[(uint32_t)(y1 * img.width + x0)] * (1.0f / 255.0f), t11 = p[(uint32_t)(y1 * img.width + x1)] * (1.0f / 255.0f);
         out[0] = (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
     }
 }
@@ -941,21 +954,21 @@ __device__ __forceinline__ void tex2d(const DevImage& img, float u, float v, flo
 // walk down the texture indices; the host guarantees the texture graph is acyclic.
 template <int FEAT = kFeatAll>
 __device__ __forceinline__ V3 texture_value(const DevScene& sc, int idx, float u, float v, V3 p) {
-    float4 t0 = sc.texs[idx * 2];
+    float4 t0 = *at32(sc.texs, idx * 2);
     if (!(FEAT & kFeatShading)) return v3(t0.y, t0.z, t0.w);     // every texture of the scene is one colour
     int type = __float_as_int(t0.x);
     for (int guard = 0; type == 1 && guard < sc.texture_count; guard++) {
-        float4 t1 = sc.texs[idx * 2 + 1];
+        float4 t1 = *at32(sc.texs, idx * 2 + 1);
         int xi = (int)floorf(t1.z * p.x), yi = (int)floorf(t1.z * p.y), zi = (int)floorf(t1.z * p.z);
         bool even = (xi + yi + zi) % 2 == 0;
         idx = even ? __float_as_int(t1.y) : __float_as_int(t1.x);
-        t0 = sc.texs[idx * 2];
+        t0 = *at32(sc.texs, idx * 2);
         type = __float_as_int(t0.x);
     }
     if (type == 0) return v3(t0.y, t0.z, t0.w);
     if (type == 2) {
-        float4 t1 = sc.texs[idx * 2 + 1];
-        const DevImage img = sc.images[__float_as_int(t1.w)];
+        float4 t1 = *at32(sc.texs, idx * 2 + 1);
+        const DevImage img = *at32(sc.images, __float_as_int(t1.w));
         u = fminf(fmaxf(u, 0.0f), 1.0f);
         v = fminf(fmaxf(v, 0.0f), 1.0f);
         float px[4];
@@ -984,8 +997,8 @@ struct Surface {
 // material or a normal map); the render never looks at them otherwise.
 template <bool ALWAYS_UV, int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r, const Hit& h) {
-    const float4* pq = sc.prims + h.obj * kPrimQuads;
-    const float4* sq = sc.shade + h.obj * kShadeQuads;
+    const float4* pq = at32(sc.prims, h.obj * kPrimQuads);
+    const float4* sq = at32(sc.shade, h.obj * kShadeQuads);
     float4 q0 = pq[0], q1 = pq[1], q2 = pq[2];
     float4 s0 = sq[0], s1 = sq[1];
     const int xf = (FEAT & kFeatXform) ? __float_as_int(q2.y) : -1, type = __float_as_int(q2.z);
@@ -1008,7 +1021,7 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
         // vertex uvs, third vertex normal, tangent frame: only where something reads them
         float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0, c3 = c0;
         if (ALWAYS_UV || (flags & 3) || normal_idx >= 0) {
-            const float4* cq = sc.shade_cold + h.obj * kShadeColdQuads;
+            const float4* cq = at32(sc.shade_cold, h.obj * kShadeColdQuads);
             c0 = cq[0]; c1 = cq[1]; c2 = cq[2]; c3 = cq[3];
         }
         V3 n;
@@ -1066,8 +1079,8 @@ __device__ __forceinline__ Surface make_surface(const DevScene& sc, const Ray& r
     }
     s.p = p;
     if (normal_idx >= 0) {                                               // apply_normal_map
-        float4 t1 = sc.texs[normal_idx * 2 + 1];
-        const DevImage img = sc.images[__float_as_int(t1.w)];
+        float4 t1 = *at32(sc.texs, normal_idx * 2 + 1);
+        const DevImage img = *at32(sc.images, __float_as_int(t1.w));
         V3 pixel = v3(0.0f, 0.0f, 1.0f);
         float px[4];
         if (img.channels == 1) {
@@ -1198,7 +1211,7 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
     }
     if (!(FEAT & kFeatMaterials)) return false;                // neither metal nor glass in the scene: a light
     if (type == 1) {                                           // metal :311-322
-        float4 m1 = sc.mats[s.mat * 2 + 1];
+        float4 m1 = *at32(sc.mats, s.mat * 2 + 1);
         V3 unit_dir = unit_vector<FAST>(in.d);
         V3 reflected = reflect(unit_dir, s.normal);
         out.o = s.p;
@@ -1232,14 +1245,14 @@ __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, 
 // material::emit (material.cuh:375-381)
 template <int FEAT = kFeatAll>
 __device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
-    float4 m0 = sc.mats[s.mat * 2];
+    float4 m0 = *at32(sc.mats, s.mat * 2);
     if (__float_as_int(m0.x) == 3) return texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
     return v3(0.0f, 0.0f, 0.0f);
 }
 // Environment lookup on a miss (render.cuh:77-82)
 template <int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ V3 environment(const DevScene& sc, V3 dir) {
-    float4 t0 = sc.texs[sc.background_index * 2];
+    float4 t0 = *at32(sc.texs, sc.background_index * 2);
     if (!(FEAT & kFeatEnvTexture) || __float_as_int(t0.x) == 0) return v3(t0.y, t0.z, t0.w);   // solid colour: (u,v,p) are not read
     V3 p = unit_vector<FAST>(dir);
     float theta = crt_det::acos(-p.y);

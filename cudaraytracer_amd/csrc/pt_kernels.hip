@@ -333,9 +333,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             CRT_CLOCK(clk, kSecSurface, h.t);
             if (h.obj >= 0) {
                 CRT_PROF(kProfShade);
-                if constexpr (MODE == kModeFlat) h.obj = A.flat.ent_obj[h.obj];
+                if constexpr (MODE == kModeFlat) h.obj = *at32(A.flat.ent_obj, h.obj);
                 sf = make_surface<false, FEAT, FAST>(sc, ray, h);
-                m0 = sc.mats[sf.mat * 2];
+                m0 = *at32(sc.mats, sf.mat * 2);
                 mat_type = __float_as_int(m0.x);
             }
         }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
         int mat_type = -1;
         if (active && h.obj >= 0) {
             sf = make_surface<false>(sc, ray, h);
-            m0 = sc.mats[sf.mat * 2];
+            m0 = *at32(sc.mats, sf.mat * 2);
             mat_type = __float_as_int(m0.x);
         }
         const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
             SectionClock clk;
             clk.start();
             h = traverse_flat<GROUPS, 0>(FL, A.flat, ray, 0.001f, INFINITY, clk);
-            if (h.obj >= 0) h.obj = A.flat.ent_obj[h.obj];
+            if (h.obj >= 0) h.obj = *at32(A.flat.ent_obj, h.obj);
         } else {
             SceneGlobal S;
             S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
@@ -1929,6 +1929,11 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         }
     }
 
+    // the kernels form byte offsets into each of these tables in 32 bits (at32), and texel numbers in an int
+    for (size_t words : {node_rec.size(), prim_rec.size(), shade_rec.size(), cold_rec.size(), xforms.size(), mat_rec.size(), tex_rec.size(), flat_ent_obj.size()})
+        if (words >= (size_t(1) << 30)) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: a scene table of 4 GiB or more is not supported");
+    for (const DevImage& im : images)
+        if ((size_t)im.width * im.height >= (size_t(1) << 31)) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: an image of 2^31 pixels or more is not supported");
     crt_scene* sc = new crt_scene();
     struct Guard {                                           // frees the half-built scene on every early exit, thrown or returned
         crt_scene* sc;
