@@ -39,12 +39,17 @@ namespace crt {
 //   -DCRT_PROFILE -DCRT_PROFILE_CLOCK  instead, the shader-clock time of the waves per section of the
 //                                      path loop (slots 32..39); the counters' atomics would dominate
 //                                      those times, so the two are separate builds.
+// The lanes of the wave on which `p` holds, as a 64-bit mask in scalar registers.  (HIP's __ballot takes an
+// int: the predicate is first turned into 0 / 1 in a vector register and compared with zero again, two
+// instructions more per use.)
+__device__ __forceinline__ unsigned long long lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 #ifdef CRT_PROFILE
 __device__ unsigned long long g_prof[64];
 #endif
 #if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
 __device__ __forceinline__ void prof_tick(int site) {
-    unsigned long long m = __ballot(1);
+    unsigned long long m = lanes_where(true);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) {
         atomicAdd(&g_prof[2 * site], 1ull);
         atomicAdd(&g_prof[2 * site + 1], (unsigned long long)__builtin_popcountll(m));
@@ -420,10 +425,14 @@ __device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd
 // open one (:287-289).  With `rank` = position of a primitive in that order, "tested later wins
 // a tie if it is a triangle, never if it is a sphere" reproduces the reference's choice in any
 // test order.  best.obj holds the rank of the best candidate so far.
+// ALL_TRI: the scene holds nothing but triangles, so the best candidate so far is one and `best_tri` is
+// neither read nor written (a flag less to carry round the loops).
+template <bool ALL_TRI = false>
 __device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, float t, int rank, bool is_tri, float bu, float bv) {
-    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? is_tri : !best_tri);
+    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? (ALL_TRI || is_tri) : (ALL_TRI ? false : !best_tri));
     if (ok && (t < best.t || (t == best.t && win_tie))) {
-        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_tri = is_tri;
+        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv;
+        if (!ALL_TRI) best_tri = is_tri;
     }
 }
 
@@ -478,7 +487,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
     if (!(FEAT & kFeatSphere) || type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
         const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, FAST, t, bu, bv);
-        consider(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
+        consider<!(FEAT & kFeatSphere)>(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
     } else {
         // the root the reference would take does not depend on the interval's upper end: the
         // near root if it is beyond tmin, else the far one (hittable.cuh:283-289)
@@ -488,6 +497,17 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
     }
     if (ts.best.obj != before) ts.best_obj = obj;
 }
+
+// The two per-lane tests of tree_run's loop as ONE compare each (a test that combines several compares reaches the
+// lane mask through scalar and/or instructions and a detour through a vector register).
+// `next` is a stack entry (node * 2 + leafy, >= 0) or -1.
+//   can_step: a node to visit, and no untested candidates in front of a leafy node: the blocked case sets the sign bit
+__device__ __forceinline__ bool can_step(int next, unsigned leaf_mask) {
+    const unsigned blocked = (unsigned)next & (leaf_mask < 1u ? leaf_mask : 1u);
+    return (int)((unsigned)next | (blocked << 31)) >= 0;
+}
+//   still_walking: a node to visit or candidates to test
+__device__ __forceinline__ bool still_walking(int next, unsigned leaf_mask) { return (((unsigned)next + 1u) | leaf_mask) != 0u; }
 
 // One wave-wide loop; in every round
 //   * each lane that can takes ONE node step (box tests of the four slots, pushes, pop).  A lane
@@ -517,11 +537,17 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
     const bool oct_word = (oct_entry & 2) != 0;
     const int oct_shift = (oct_entry & 1) * 16;
 
+    // A lane that is not walking holds no node and no candidates, so `walking` drops out of every test
+    // of the loop.  The lanes that take a node step are kept as a lane mask in scalar registers: it is
+    // evaluated once per round (it also decides whether the candidates are tested now) and again only
+    // after a round of primitive tests; the branch around the node step takes it as it is.
+    int next = walking ? ts.node : -1;
+    unsigned leaf_mask = walking ? ts.leaf_mask : 0u;
+    unsigned long long stepping = lanes_where(can_step(next, leaf_mask));
     while (true) {                                                  // wave-uniform
-        const bool node_step = walking && ts.node >= 0 && !((ts.node & 1) && ts.leaf_mask);
-        if (node_step) {
+        if (__builtin_amdgcn_inverse_ballot_w64(stepping)) {
             CRT_PROF(kProfNode);
-            const int node = ts.node >> 1;
+            const int node = next >> 1;
             float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
             float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
             float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
@@ -574,19 +600,19 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 ts.sp += __builtin_popcount(push_mask);
             }
             if (leaf_hits) {                                        // only reached with no candidates pending
-                ts.leaf_mask = leaf_hits;
+                leaf_mask = leaf_hits;
                 stk.code[0] = codes[0]; stk.code[stk.stride] = codes[1]; stk.code[2 * stk.stride] = codes[2]; stk.code[3 * stk.stride] = codes[3];
                 stk.entry[0] = los[0]; stk.entry[stk.stride] = los[1]; stk.entry[2 * stk.stride] = los[2]; stk.entry[3 * stk.stride] = los[3];
             }
-            ts.node = ts.sp ? stk.get(--ts.sp) : -1;
+            next = ts.sp ? stk.get(--ts.sp) : -1;
         }
-        const bool has_prim = walking && ts.leaf_mask != 0;
-        const int pending = __builtin_popcountll(__ballot(has_prim));
-        const bool more_nodes = __any(walking && ts.node >= 0 && !((ts.node & 1) && ts.leaf_mask));
-        if (pending && (pending >= prim_batch || !more_nodes)) {
+        const bool has_prim = leaf_mask != 0;
+        const int pending = __builtin_popcountll(lanes_where(has_prim));
+        stepping = lanes_where(can_step(next, leaf_mask));
+        if (pending && (pending >= prim_batch || !stepping)) {
             if (has_prim) {
-                const int i = __builtin_ctz(ts.leaf_mask);
-                ts.leaf_mask &= ts.leaf_mask - 1;
+                const int i = __builtin_ctz(leaf_mask);
+                leaf_mask &= leaf_mask - 1;
                 const int code = stk.code[i * stk.stride];
                 const float lo = stk.entry[i * stk.stride];
                 // an earlier candidate may have shrunk the interval below this box's entry
@@ -595,10 +621,13 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                     tree_prim<FAST, FEAT>(S, code, r, tmin, ts);
                 }
             }
+            stepping = lanes_where(can_step(next, leaf_mask));
         }
-        if (walking && ts.node < 0 && ts.leaf_mask == 0) walking = false;
-        if (__builtin_popcountll(__ballot(walking)) < min_active) break;
+        if (__builtin_popcountll(lanes_where(still_walking(next, leaf_mask))) < min_active) break;
     }
+    ts.node = next;
+    ts.leaf_mask = leaf_mask;
+    walking = still_walking(next, leaf_mask);
 }
 
 // One whole walk (used where no lane is refilled in between).
@@ -891,12 +920,12 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
         if (!(FEAT & kFeatSphere) || is_tri) {
             const TriEval A = tri_eval(o, d, v3(q0.z, q0.w, q1.x), v3(q1.y, q1.z, q1.w), v3(q2.x, q2.y, q2.z), tmin, tmax, FAST);
-            consider(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
+            consider<!(FEAT & kFeatSphere)>(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
             float bx = q2.w;
             asm volatile("" : "+v"(bx) : : "memory");              // keeps the two loads below behind triangle A
             const float4 q3 = rec[3], q4 = rec[4];
             const TriEval B = tri_eval(o, d, v3(bx, q3.x, q3.y), v3(q3.z, q3.w, q4.x), v3(q4.y, q4.z, q4.w), tmin, tmax, FAST);
-            consider(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
+            consider<!(FEAT & kFeatSphere)>(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
         } else {
             // sphere slot: {c0.xyz, radius} {cd.xyz, 0}.  The root the reference would take does not
             // depend on the upper bound: the near root if it is beyond tmin, else the far one.
@@ -1152,7 +1181,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
         rng.draws += 3;
         pending = !sample_accepted(out, in_sphere);
     }
-    unsigned long long mask = __ballot(pending);
+    unsigned long long mask = lanes_where(pending);
     while (mask) {                                          // wave-uniform
         CRT_PROF(kProfReject);
         const int pending_count = __builtin_popcountll(mask);
@@ -1172,7 +1201,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
             ok = sample_accepted(p, (word >> 31) != 0);
             res[3 * lane] = p.x; res[3 * lane + 1] = p.y; res[3 * lane + 2] = p.z;
         }
-        const unsigned long long okmask = __ballot(ok);
+        const unsigned long long okmask = lanes_where(ok);
         wave_lds_sync();
         if (pending) {
             const unsigned sub = (unsigned)(okmask >> (rank << log2m)) & ((1u << m) - 1u);
@@ -1187,7 +1216,7 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
             }
         }
         wave_lds_sync();                                    // the next round overwrites pub and res
-        mask = __ballot(pending);
+        mask = lanes_where(pending);
     }
     if (need && !in_sphere) out = unit_vector<FAST>(out);
     return out;

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         if (draining) {
             const int drain_base = (fill_buffer ^ 1) * kAccFloatsPerTile;
             const bool mine = alive && ((pixoff >= kAccFloatsPerTile) == (drain_base != 0));
-            if (!__any(mine)) {
+            if (!lanes_where(mine)) {
                 flush(fill_buffer ^ 1, drain_tile, drain_chunk);
                 draining = false;
             }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             fill = fetch();
         }
         if (fill.next < fill.total) {                             // wave-uniform
-            const unsigned long long free_mask = __ballot(!alive);
+            const unsigned long long free_mask = lanes_where(!alive);
             if (!alive) {
                 CRT_PROF(kProfRegen);
                 const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             fill.next += __builtin_popcountll(free_mask);
         }
         CRT_CLOCK(clk, kSecOther, ray.o.x);
-        if (!__any(alive)) {
+        if (!lanes_where(alive)) {
             if (!fill.valid && !draining) break;                  // queue empty and everything flushed
             continue;
         }
@@ -315,13 +315,13 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         bool ready = alive;
         if constexpr (MODE != kModeFlat) {
             CRT_CLOCK(clk, kSecNode, ray.o.y);
-            const int living = __builtin_popcountll(__ballot(alive));
+            const int living = __builtin_popcountll(lanes_where(alive));
             const int ready_target = max(1, living * A.ready_percent / 100);
             if constexpr (MODE == kModeTreeLds) tree_run<FAST, FEAT>(SL, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
             else tree_run<FAST, FEAT>(SG, ray, 0.001f, ts, walking, stk, living - ready_target + 1, A.prim_batch);
             ready = alive && !walking;
         }
-        rays += (unsigned int)__builtin_popcountll(__ballot(ready));   // one count per wave, in a scalar register
+        rays += (unsigned int)__builtin_popcountll(lanes_where(ready));   // one count per wave, in a scalar register
         if (ready) {
             CRT_PROF(kProfTrace);
             if constexpr (MODE == kModeFlat) {
@@ -515,7 +515,7 @@ constexpr int kWfCursorStride = 32;  // unsigned ints between cursors: 128 bytes
 // Position in the segment's output for the lanes of this wave that keep a path (`keep`): the
 // workgroup's running count lives in LDS.
 __device__ __forceinline__ unsigned int wf_segment_slot(bool keep, unsigned int* lds_count, int lane) {
-    const unsigned long long mask = __ballot(keep);
+    const unsigned long long mask = lanes_where(keep);
     unsigned int off = 0;
     if (lane == 0 && mask) off = atomicAdd(lds_count, (unsigned int)__builtin_popcountll(mask));
     return __builtin_amdgcn_readfirstlane(off) + (unsigned int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(
     while (true) {
         // hand rays to the lanes without one
         while (!dry) {
-            const unsigned long long idle = __ballot(!walking);
+            const unsigned long long idle = lanes_where(!walking);
             if (!idle) break;
             if (have_lo == have_hi) {
                 unsigned int k = 0;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(
                     // this list has run out: look at all cursors at once (lane l reads list l's) and
                     // move to the next list that still has segments, if any
                     const unsigned int seen = __hip_atomic_load(&cursors[lane * kWfCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long open = __ballot((unsigned long long)seen * kWfCursors + (unsigned int)lane < (unsigned long long)A.segments);
+                    const unsigned long long open = lanes_where((unsigned long long)seen * kWfCursors + (unsigned int)lane < (unsigned long long)A.segments);
                     if (!open) { dry = true; break; }
                     const unsigned long long after = open & ~((2ull << list) - 1ull);
                     list = after ? __builtin_ctzll(after) : __builtin_ctzll(open);
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(
             }
             have_lo += take;
         }
-        const int active = __builtin_popcountll(__ballot(walking));
+        const int active = __builtin_popcountll(lanes_where(walking));
         if (active == 0) break;
         // walk until 8 lanes have finished (or, with the queue dry, until every walk has ended)
         const bool was = walking;
