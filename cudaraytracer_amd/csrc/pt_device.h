@@ -239,14 +239,19 @@ __device__ __forceinline__ const T* at32(const T* base, int index) {
 // ------------------------------------------------------------------ scene memory views --
 // Two views with the same interface: HBM (node-major records, served by L1/L2) and an LDS
 // copy (field-major, so that lanes on different nodes fall on different banks).
+// A reference to a node, in a slot code of its parent and on the traversal stack: node index * kNodeEntryScale +
+// leafy (bit 0: the node has leaf slots of its own), >= 0; -1 = none.
+constexpr int kNodeEntryScale = 128;
 struct SceneGlobal {
     const float4* nodes;
     const float4* prims;
     const float* xforms;
     int root_entry;        // stack entry of node 0
     int order_flip;        // 15: rays towards -z read a node's slot order backwards; 0: one order for every ray (reference-order walk)
-    __device__ __forceinline__ float4 node_field(int node, int field) const {
-        return *at32(nodes, node * kNodeStrideGlobal + field);
+    // entry: a stack entry, node * 128 + leafy = the byte offset of the node's record (128 bytes) + its flag
+    __device__ __forceinline__ float4 node_field(int entry, int field) const {
+        static_assert(kNodeStrideGlobal * 16 == kNodeEntryScale, "a stack entry is a byte offset into the node records");
+        return *(const float4*)((const char*)nodes + (((uint32_t)entry & ~(uint32_t)(kNodeEntryScale - 1)) + (uint32_t)field * 16u));
     }
     __device__ __forceinline__ float4 prim(int obj, int q) const {
         return *at32(prims, obj * kPrimQuads + q);
@@ -260,7 +265,7 @@ struct SceneLds {
     int node_count, object_count;
     int root_entry;
     int order_flip;
-    __device__ __forceinline__ float4 node_field(int node, int field) const { return nodes[field * node_count + node]; }
+    __device__ __forceinline__ float4 node_field(int entry, int field) const { return nodes[field * node_count + entry / kNodeEntryScale]; }
     __device__ __forceinline__ float4 prim(int obj, int q) const { return prims[q * object_count + obj]; }
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
 };
@@ -288,6 +293,15 @@ struct LaneStack {
     LdsFloatPtr entry;
     GlobalIntPtr spill;
     size_t spill_stride;
+    // The LDS part is `rows` rows of `threads` words.  Row 0 holds -1 for every lane and is what a pop from an
+    // empty stack reads ("no node left": the pop needs no test for the empty stack); entry e of this lane is at
+    // base[e * stride] with base in row 1.
+    __device__ __forceinline__ void attach(int* lds_rows, int rows, int threads, int thread) {
+        lds_rows[thread] = -1;
+        base = (LdsIntPtr)(lds_rows + threads + thread);
+        stride = threads;
+        lds_entries = rows - 1;
+    }
     __device__ __forceinline__ void put(int e, int v) {
         if (e < lds_entries) base[e * stride] = v;
         else spill[(size_t)(e - lds_entries) * spill_stride] = v;
@@ -457,7 +471,7 @@ __device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, flo
 // still walking; the caller shades the finished lanes, gives them new rays and calls again,
 // and the unfinished lanes simply continue from their saved state (registers + LDS stack).
 struct TreeState {
-    int node, sp;                       // next node to visit as a stack entry: index*2 + leafy (-1: none left), stack height
+    int node, sp;                       // next node to visit as a stack entry: index * kNodeEntryScale + leafy (-1: none left), stack height
     unsigned leaf_mask;                 // pending leaf slots of the last visited node
                                         // (its slot codes and box entry distances: LaneStack::code, ::entry)
     Hit best;                           // best.obj = visiting rank while walking
@@ -500,7 +514,7 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
 
 // The two per-lane tests of tree_run's loop as ONE compare each (a test that combines several compares reaches the
 // lane mask through scalar and/or instructions and a detour through a vector register).
-// `next` is a stack entry (node * 2 + leafy, >= 0) or -1.
+// `next` is a stack entry (node * kNodeEntryScale + leafy, >= 0) or -1.
 //   can_step: a node to visit, and no untested candidates in front of a leafy node: the blocked case sets the sign bit
 __device__ __forceinline__ bool can_step(int next, unsigned leaf_mask) {
     const unsigned blocked = (unsigned)next & (leaf_mask < 1u ? leaf_mask : 1u);
@@ -547,11 +561,10 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
     while (true) {                                                  // wave-uniform
         if (__builtin_amdgcn_inverse_ballot_w64(stepping)) {
             CRT_PROF(kProfNode);
-            const int node = next >> 1;
-            float4 bnx = S.node_field(node, nx), bfx = S.node_field(node, fx);
-            float4 bny = S.node_field(node, ny), bfy = S.node_field(node, fy);
-            float4 bnz = S.node_field(node, nz), bfz = S.node_field(node, fz);
-            float4 codef = S.node_field(node, 6), orderf = S.node_field(node, 7);
+            float4 bnx = S.node_field(next, nx), bfx = S.node_field(next, fx);
+            float4 bny = S.node_field(next, ny), bfy = S.node_field(next, fy);
+            float4 bnz = S.node_field(next, nz), bfz = S.node_field(next, fz);
+            float4 codef = S.node_field(next, 6), orderf = S.node_field(next, 7);
             const float nxs[4] = {bnx.x, bnx.y, bnx.z, bnx.w}, fxs[4] = {bfx.x, bfx.y, bfx.z, bfx.w};
             const float nys[4] = {bny.x, bny.y, bny.z, bny.w}, fys[4] = {bfy.x, bfy.y, bfy.z, bfy.w};
             const float nzs[4] = {bnz.x, bnz.y, bnz.z, bnz.w}, fzs[4] = {bfz.x, bfz.y, bfz.z, bfz.w};
@@ -580,21 +593,22 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
             // internal children onto the stack, farthest first, so that the nearest is popped first:
             // a slot's place above the old top is the number of pushed slots visited after it
             if (push_mask) {
-                if (ts.sp + 4 <= stk.lds_entries) {
+                if (!lanes_where(ts.sp + 4 > stk.lds_entries)) {        // decided for the wave: two instructions instead of a divergent if / else
                     // every slot writes, without a branch: the ones that are not pushed to a word above the new top
+                    const int first = ts.sp + self, unused = ts.sp + 3;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const unsigned after = ((order >> (4 * i)) & 15u) ^ flip;
-                        const int place = __builtin_popcount(after & push_mask) + self;
+                        const int place = __builtin_popcount(after & push_mask) + first;
                         const bool pushed = (push_mask >> i) & 1u;
-                        stk.base[(ts.sp + (pushed ? place : 3)) * stk.stride] = -codes[i] - 2;
+                        stk.base[(pushed ? place : unused) * stk.stride] = codes[i];
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const unsigned after = ((order >> (4 * i)) & 15u) ^ flip;
                         const int place = __builtin_popcount(after & push_mask) + self;
-                        if ((push_mask >> i) & 1u) stk.put(ts.sp + place, -codes[i] - 2);
+                        if ((push_mask >> i) & 1u) stk.put(ts.sp + place, codes[i]);
                     }
                 }
                 ts.sp += __builtin_popcount(push_mask);
@@ -604,7 +618,10 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 stk.code[0] = codes[0]; stk.code[stk.stride] = codes[1]; stk.code[2 * stk.stride] = codes[2]; stk.code[3 * stk.stride] = codes[3];
                 stk.entry[0] = los[0]; stk.entry[stk.stride] = los[1]; stk.entry[2 * stk.stride] = los[2]; stk.entry[3 * stk.stride] = los[3];
             }
-            next = ts.sp ? stk.get(--ts.sp) : -1;
+            // pop; -1 from the row below an empty stack (sp is then -1 until the lane's next walk begins)
+            --ts.sp;
+            if (!lanes_where(ts.sp >= stk.lds_entries)) next = stk.base[ts.sp * stk.stride];
+            else next = stk.get(ts.sp);
         }
         const bool has_prim = leaf_mask != 0;
         const int pending = __builtin_popcountll(lanes_where(has_prim));

@@ -190,9 +190,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     __syncthreads();
 
     LaneStack stk;
-    stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
-    stk.stride = kBlock;
-    stk.lds_entries = STACK;
+    stk.attach(stack_mem, STACK, kBlock, threadIdx.x);
     stk.entry = (LdsFloatPtr)(entry_mem + threadIdx.x);
     stk.code = (LdsIntPtr)(reinterpret_cast<int*>(entry_mem) + 4 * kBlock + threadIdx.x);
     stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
@@ -574,9 +572,7 @@ __global__ __launch_bounds__(kBlock, CRT_WF_TRACE_WAVES_PER_SIMD) void wf_trace(
     SceneGlobal S;
     S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
     LaneStack stk;
-    stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
-    stk.stride = kBlock;
-    stk.lds_entries = STACK;
+    stk.attach(stack_mem, STACK, kBlock, threadIdx.x);
     stk.entry = (LdsFloatPtr)(reinterpret_cast<float*>(stack_mem + STACK * kBlock) + threadIdx.x);
     stk.code = (LdsIntPtr)(stack_mem + (STACK + 4) * kBlock + threadIdx.x);
     stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
@@ -864,9 +860,7 @@ __global__ __launch_bounds__(kBlock) void trace_primary_kernel(PrimaryArgs A) {
             SceneGlobal S;
             S.nodes = sc.nodes; S.prims = sc.prims; S.xforms = sc.xforms; S.root_entry = sc.root_entry; S.order_flip = sc.order_flip;
             LaneStack stk;
-            stk.base = (LdsIntPtr)(stack_mem + threadIdx.x);
-            stk.stride = kBlock;
-            stk.lds_entries = STACK;
+            stk.attach(stack_mem, STACK, kBlock, threadIdx.x);
             stk.entry = (LdsFloatPtr)(reinterpret_cast<float*>(stack_mem + STACK * kBlock) + threadIdx.x);
             stk.code = (LdsIntPtr)(stack_mem + (STACK + 4) * kBlock + threadIdx.x);
             stk.spill = (GlobalIntPtr)(A.stack_spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
@@ -1005,7 +999,7 @@ struct crt_scene {
     std::vector<void*> image_mem;
     DevScene dev = {};
     crt_render_info render = {};
-    int stack_entries = 8;           // LDS entries of the traversal stack (8 or 12)
+    int stack_entries = 8;           // LDS rows of the traversal stack (8 or 12): one row of -1 and 7 or 11 entries
     int spill_entries = 0;           // entries beyond them, in global memory
     int spill_threads = 0;
     int* stack_spill = nullptr;
@@ -1541,11 +1535,13 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         need = 3 * (accel_depth - 1) + 1;
     }
     if (need > 1024) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: hierarchy deeper than 342 levels");
-    // LDS part of the traversal stack: 8 entries for shallow trees, else 12 (deeper entries go to the
-    // global part; with the 8 words of pending candidates beside it a workgroup stays under 40 KB)
-    const int stack_entries = need <= 8 ? 8 : 12;
+    // LDS part of the traversal stack: 8 rows for shallow trees, else 12, one of them the row of -1 below the
+    // stacks (deeper entries go to the global part; with the 8 words of pending candidates beside it a
+    // workgroup stays under 40 KB)
+    const int stack_entries = need <= 7 ? 8 : 12;
 
     const int nodes = (int)accel.size();
+    if (accel.size() >= (size_t(1) << 31) / kNodeEntryScale) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: more than 16 million hierarchy nodes are not supported");
     auto accel_leafy = [&](int node) {
         for (int i = 0; i < 4; i++)
             if (accel[(size_t)node].object[i] >= 0) return true;
@@ -1562,9 +1558,10 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                 rec[(3 + a) * 4 + i] = an.hi[i][a];
             }
             const int o = an.object[i], c = an.child[i];
-            // slot code: object index, or -(2*child + leafy) - 2 for an internal slot, or -1 (empty);
-            // leafy = the child node has leaf slots of its own
-            int32_t code = o >= 0 ? o : (c >= 0 ? -(2 * c + (accel_leafy(c) ? 1 : 0)) - 2 : -1);
+            // slot code: object index of a leaf slot, the child's stack entry (child * kNodeEntryScale + leafy;
+            // leafy = the child node has leaf slots of its own) of an internal slot, -1 for an empty one;
+            // which of the three a slot is stands in the `kinds` word below
+            int32_t code = o >= 0 ? o : (c >= 0 ? c * kNodeEntryScale + (accel_leafy(c) ? 1 : 0) : -1);
             rec[6 * 4 + i] = as_float(code);
         }
         // Visiting order of the four slots for the direction octants 0-3 (bit 0/1 set: the ray runs
@@ -1977,7 +1974,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
-    sc->spill_entries = std::max(0, need - stack_entries);
+    sc->spill_entries = std::max(0, need - (stack_entries - 1));       // one LDS row is the row of -1 below the stacks
     sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), CRT_TREE_WAVES_PER_SIMD), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
         CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
