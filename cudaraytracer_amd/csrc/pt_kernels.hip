@@ -42,6 +42,12 @@ namespace crt {
 #ifndef CRT_FLAT_WAVES_PER_SIMD
 #define CRT_FLAT_WAVES_PER_SIMD 5
 #endif
+#ifndef CRT_TREE_BASIC_WAVES_PER_SIMD
+#define CRT_TREE_BASIC_WAVES_PER_SIMD 4      // tree walk over untransformed triangles only
+#endif
+#ifndef CRT_TREE_TILE_ROWS
+#define CRT_TREE_TILE_ROWS 4
+#endif
 #ifndef CRT_TREE_WAVES_PER_SIMD
 #define CRT_TREE_WAVES_PER_SIMD 4
 #endif
@@ -54,8 +60,11 @@ constexpr int kTileW = 8;
 #ifndef CRT_FLAT_TILE_ROWS
 #define CRT_FLAT_TILE_ROWS 4
 #endif
-constexpr int tile_rows(int mode) { return mode == 2 ? CRT_FLAT_TILE_ROWS : 4; }
-constexpr int waves_per_simd(int mode, int feat) { return mode != 2 ? CRT_TREE_WAVES_PER_SIMD : (feat == kFeatBasicXform ? CRT_FLAT_BASIC_WAVES_PER_SIMD : CRT_FLAT_WAVES_PER_SIMD); }
+constexpr int tile_rows(int mode) { return mode == 2 ? CRT_FLAT_TILE_ROWS : CRT_TREE_TILE_ROWS; }
+constexpr int waves_per_simd(int mode, int feat) {
+    if (mode != 2) return feat == kFeatBasic ? CRT_TREE_BASIC_WAVES_PER_SIMD : CRT_TREE_WAVES_PER_SIMD;
+    return feat == kFeatBasicXform ? CRT_FLAT_BASIC_WAVES_PER_SIMD : CRT_FLAT_WAVES_PER_SIMD;
+}
 
 // How a kernel reaches the scene geometry
 enum : int {
@@ -135,7 +144,7 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
 }
 
 // LDS carve-up of a block: [pass sums: waves x 2 x 14 x 32 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
-constexpr int kCoopWordsPerWave = 128 + 192;    // coop_sphere_sample: published streams + candidate points
+constexpr int kCoopWordsPerWave = 192;          // coop_sphere_sample: published streams (128 words), then candidate points (192) over them
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
 constexpr int kParkWords = 3;                    // flat mode: per-lane path state kept in LDS
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][tile pixels] sums of the wave's two open tiles
     uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
-    float* coop_res = reinterpret_cast<float*>(coop_pub + 128);
+    // (every lane has read the published streams before any lane stores a candidate point: one wave, LDS in order)
+    float* coop_res = reinterpret_cast<float*>(coop_pub);
 #pragma unroll
     for (int k = 0; k < kAccFloatsPerWave / 64; k++) acc[k * 64 + lane] = 0.0f;
 
@@ -665,7 +675,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
     const DevScene& sc = A.sc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
-    float* coop_res = reinterpret_cast<float*>(coop_pub + 128);
+    // (every lane has read the published streams before any lane stores a candidate point: one wave, LDS in order)
+    float* coop_res = reinterpret_cast<float*>(coop_pub);
     const size_t cap = (size_t)A.batch_capacity;
     for (int seg = blockIdx.x; seg < A.segments; seg += gridDim.x) {
         __syncthreads();
@@ -1975,7 +1986,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
     sc->spill_entries = std::max(0, need - (stack_entries - 1));       // one LDS row is the row of -1 below the stacks
-    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), CRT_TREE_WAVES_PER_SIMD), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
+    sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), std::max(CRT_TREE_WAVES_PER_SIMD, CRT_TREE_BASIC_WAVES_PER_SIMD)), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
         CRT_HIP_OR_FREE(hipMalloc((void**)&sc->stack_spill, (size_t)sc->spill_entries * sc->spill_threads * sizeof(int)));
     }
