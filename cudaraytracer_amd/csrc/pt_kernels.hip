@@ -147,14 +147,16 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
 constexpr int kCoopWordsPerWave = 192;          // coop_sphere_sample: published streams (128 words), then candidate points (192) over them
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
+constexpr int kItemWords = 8;                    // per wave: the cold part of its work items (tile position, first sample, ...)
 constexpr int kParkWords = 3;                    // flat mode: per-lane path state kept in LDS
 static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
-constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave) * 4 + kCamWords * 4 / kWaves; }
+constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave + kItemWords) * 4 + kCamWords * 4 / kWaves; }
 
 // One work item of a wave: the 8x4 pixel tile `tile`, samples [s0, s0 + items/32).
 struct WorkItem {
-    int tile, chunk, tx, ty, s0, next, total;
+    int next, total;
     bool valid;
+    int tile, chunk, tx, ty, s0;      // (tree modes; the flat mode keeps these in LDS)
 };
 
 // The path tracer.  Persistent waves: the grid is sized to fill the chip once, and every wave
@@ -173,12 +175,26 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     // sit in scalar registers for the whole kernel, and the compiler, out of scalar registers,
     // parks them in lanes of a vector register and fetches each one back with a v_readlane.
     DevCamera* lds_cam = reinterpret_cast<DevCamera*>(coop_all + kWaves * kCoopWordsPerWave);
-    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords);
+    // Flat mode: work-item values that are the same for every lane and only read where a path starts or an
+    // item is flushed live here, one copy per wave, instead of in a vector register per value for the whole
+    // kernel (the compiler does not keep them in scalar registers, and at 80 registers they end up in scratch
+    // memory): {tx, ty, first sample, -, tile, chunk, tile and chunk of the draining item}.  The tree modes
+    // have the registers (cap 128) and are faster with them.
+    constexpr bool kItemInLds = MODE == kModeFlat;
+    typedef volatile int __attribute__((address_space(3))) * LdsVolatileIntPtr;
+    LdsVolatileIntPtr item_mem = (LdsVolatileIntPtr)(reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords) + (threadIdx.x >> 6) * kItemWords);
+    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * kItemWords);
     float* entry_mem = reinterpret_cast<float*>(stack_mem + STACK * kBlock);      // tree modes: 4 slot codes + 4 box entry distances per lane
     // Flat mode: the albedo a path shows in the albedo pass is found at its first hit and only added when
     // the path ends (an exhausted path shows black, render.cuh:96-97); it waits in LDS, three words per
     // lane, instead of three registers that would be live through every traversal in between.
-    float* park = entry_mem + threadIdx.x;
+    // (the lane's address is formed anew at each use, one instruction: computed once, it is a register that is live
+    // through the whole kernel - or a spill slot in scratch memory that is loaded back at every use)
+    auto park_of_lane = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return entry_mem + t;
+    };
     float4* lds_scene = reinterpret_cast<float4*>(entry_mem + (MODE == kModeFlat ? kParkWords * kBlock : 8 * kBlock));
     const DevScene& sc = A.sc;
     if (threadIdx.x == 0) *lds_cam = sc.cam;
@@ -209,18 +225,28 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     const int item_count = A.ntiles * A.chunks;
     // next work item of this wave (wave-uniform); invalid once the counter has run past the end
     auto fetch = [&]() {
-        WorkItem w;
+        WorkItem w = {};
         unsigned int q = 0;
         if (lane == 0) q = atomicAdd(A.queue, 1u);
         q = __builtin_amdgcn_readfirstlane(q);
         w.valid = q < (unsigned int)item_count;
-        w.chunk = (int)(q / (unsigned int)A.ntiles);
-        w.tile = (int)q - w.chunk * A.ntiles;
-        w.tx = w.tile % A.tiles_x;
-        w.ty = band_global_tile_row(w.tile / A.tiles_x, A.band_tiles, A.band_index, A.band_count);
-        w.s0 = A.first_sample + w.chunk * A.chunk_size;
-        const int s1 = min(w.s0 + A.chunk_size, A.first_sample + A.samples);
-        w.total = w.valid ? (s1 - w.s0) * kTilePixels : 0;
+        const int chunk = (int)(q / (unsigned int)A.ntiles);
+        const int tile = (int)q - chunk * A.ntiles;
+        const int s0 = A.first_sample + chunk * A.chunk_size;
+        const int s1 = min(s0 + A.chunk_size, A.first_sample + A.samples);
+        const int tx = tile % A.tiles_x, ty = band_global_tile_row(tile / A.tiles_x, A.band_tiles, A.band_index, A.band_count);
+        if constexpr (kItemInLds) {
+            if (lane == 0) {
+                item_mem[0] = tx;
+                item_mem[1] = ty;
+                item_mem[2] = s0;
+                item_mem[4] = tile;
+                item_mem[5] = chunk;
+            }
+        } else {
+            w.tx = tx; w.ty = ty; w.s0 = s0; w.tile = tile; w.chunk = chunk;
+        }
+        w.total = w.valid ? (s1 - s0) * kTilePixels : 0;
         w.next = 0;
         return w;
     };
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     WorkItem fill = fetch();                                      // wave-uniform state
     int fill_buffer = 0;
     bool draining = false;                                        // the other buffer holds an item whose paths are still running
-    int drain_tile = 0, drain_chunk = 0;
+    int drain_tile = 0, drain_chunk = 0;                          // (tree modes)
 
     unsigned int rays = 0;
     bool alive = false;
@@ -250,11 +276,11 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);       // (pend_albedo: tree modes; flat mode keeps it in `park`)
     auto set_pending_albedo = [&](V3 a) {
-        if constexpr (MODE == kModeFlat) { park[0] = a.x; park[kBlock] = a.y; park[2 * kBlock] = a.z; }
+        if constexpr (MODE == kModeFlat) { float* park = park_of_lane(); park[0] = a.x; park[kBlock] = a.y; park[2 * kBlock] = a.z; }
         else pend_albedo = a;
     };
     auto pending_albedo = [&]() {
-        if constexpr (MODE == kModeFlat) return v3(park[0], park[kBlock], park[2 * kBlock]);
+        if constexpr (MODE == kModeFlat) { const float* park = park_of_lane(); return v3(park[0], park[kBlock], park[2 * kBlock]); }
         else return pend_albedo;
     };
     int bounces = 0;
@@ -274,14 +300,19 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             const int drain_base = (fill_buffer ^ 1) * kAccFloatsPerTile;
             const bool mine = alive && ((pixoff >= kAccFloatsPerTile) == (drain_base != 0));
             if (!lanes_where(mine)) {
-                flush(fill_buffer ^ 1, drain_tile, drain_chunk);
+                if constexpr (kItemInLds) flush(fill_buffer ^ 1, item_mem[6], item_mem[7]);
+                else flush(fill_buffer ^ 1, drain_tile, drain_chunk);
                 draining = false;
             }
         }
         // the fill item has handed out all its paths: let it drain and open the next one
         if (fill.valid && fill.next >= fill.total && !draining) {
             draining = true;
-            drain_tile = fill.tile; drain_chunk = fill.chunk;
+            if constexpr (kItemInLds) {
+                if (lane == 0) { item_mem[6] = item_mem[4]; item_mem[7] = item_mem[5]; }
+            } else {
+                drain_tile = fill.tile; drain_chunk = fill.chunk;
+            }
             fill_buffer ^= 1;
             fill = fetch();
         }
@@ -292,8 +323,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                 const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
                 if (item < fill.total) {
                     const int pix = item & (kTilePixels - 1);
-                    const int sample = fill.s0 + item / kTilePixels + 1;  // sample numbers are 1-based (render.cuh:128)
-                    const int pi = fill.tx * kTileW + (pix & 7), pj = fill.ty * kTileH + (pix >> 3);
+                    const int s0 = kItemInLds ? item_mem[2] : fill.s0, tx = kItemInLds ? item_mem[0] : fill.tx, ty = kItemInLds ? item_mem[1] : fill.ty;
+                    const int sample = s0 + item / kTilePixels + 1;       // sample numbers are 1-based (render.cuh:128)
+                    const int pi = tx * kTileW + (pix & 7), pj = ty * kTileH + (pix >> 3);
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
                         pixoff = fill_buffer * kAccFloatsPerTile + pix;
                         rng.init(pj * sc.width + pi, sample);
