@@ -45,6 +45,10 @@ namespace crt {
 #ifndef CRT_TREE_BASIC_WAVES_PER_SIMD
 #define CRT_TREE_BASIC_WAVES_PER_SIMD 4      // tree walk over untransformed triangles only
 #endif
+#ifndef CRT_DEEP_STACK_ROWS
+#define CRT_DEEP_STACK_ROWS 12
+#endif
+constexpr int kDeepStackRows = CRT_DEEP_STACK_ROWS;   // LDS rows of the traversal stack for trees that need more than 7 entries
 #ifndef CRT_TREE_TILE_ROWS
 #define CRT_TREE_TILE_ROWS 4
 #endif
@@ -1266,8 +1270,8 @@ int launch_fused(crt_scene* sc, const RenderArgs& A, dim3 grid) {
         CRT_HIP(hipGetLastError());
         return CRT_OK;
     }
-    if (sc->dev.fast_rcp) return sc->stack_entries == 8 ? launch_tree<8, 1>(sc, A, grid, mode) : launch_tree<12, 1>(sc, A, grid, mode);
-    return sc->stack_entries == 8 ? launch_tree<8, 0>(sc, A, grid, mode) : launch_tree<12, 0>(sc, A, grid, mode);
+    if (sc->dev.fast_rcp) return sc->stack_entries == 8 ? launch_tree<8, 1>(sc, A, grid, mode) : launch_tree<kDeepStackRows, 1>(sc, A, grid, mode);
+    return sc->stack_entries == 8 ? launch_tree<8, 0>(sc, A, grid, mode) : launch_tree<kDeepStackRows, 0>(sc, A, grid, mode);
 }
 
 // True when every divisor the kernels invert on the path (triangle determinants that pass the
@@ -1496,7 +1500,7 @@ int launch_wavefront(crt_scene* sc, const RenderArgs& A, const ChunkPlan& plan, 
         for (int b = 0; b < sc->dev.max_bounces; b++) {
             W.bounce = b;
             if (sc->stack_entries == 8) launch_wf_trace<8>(sc, W, trace_grid);
-            else launch_wf_trace<12>(sc, W, trace_grid);
+            else launch_wf_trace<kDeepStackRows>(sc, W, trace_grid);
             hipLaunchKernelGGL(wf_shade, wide, dim3(kBlock), 0, sc->stream, W);
             std::swap(W.cur, W.next);
         }
@@ -1590,7 +1594,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     // LDS part of the traversal stack: 8 rows for shallow trees, else 12, one of them the row of -1 below the
     // stacks (deeper entries go to the global part; with the 8 words of pending candidates beside it a
     // workgroup stays under 40 KB)
-    const int stack_entries = need <= 7 ? 8 : 12;
+    const int stack_entries = need <= 7 ? 8 : kDeepStackRows;
 
     const int nodes = (int)accel.size();
     if (accel.size() >= (size_t(1) << 31) / kNodeEntryScale) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_scene_create: more than 16 million hierarchy nodes are not supported");
@@ -2529,7 +2533,7 @@ int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t
         }
     } else {
         if (sc->stack_entries == 8) hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 8, 0>), grid, dim3(kBlock), (8 + 8) * kBlock * 4, sc->stream, A);
-        else hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, 12, 0>), grid, dim3(kBlock), (12 + 8) * kBlock * 4, sc->stream, A);
+        else hipLaunchKernelGGL((trace_primary_kernel<kModeTreeGlobal, kDeepStackRows, 0>), grid, dim3(kBlock), (kDeepStackRows + 8) * kBlock * 4, sc->stream, A);
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sc->stream);
