@@ -198,19 +198,23 @@ def main():
     # Frames in flight: with more than one process the collective of frame k runs while frame k+1
     # (and the start of k+2) renders, so three sets of buffers rotate; a frame's buffers are
     # rendered into again only after its collective has finished.
-    depth = 3 if distributed else 1
-    # With more than one process consecutive frames also render on two device copies of the scene (each has its
-    # own stream and scratch): a rank's share of the frame is short, and the last long paths of one frame then
-    # overlap the start of the next instead of leaving the GPU half empty (one rank's eighth of the Cornell frame:
-    # 1.44 ms per frame one at a time, 1.28-1.36 ms overlapped).  A single-GPU run keeps one frame at a time, so
-    # that the kernel durations behind the roofline are those of a kernel that has the GPU to itself.
+    # (three copies of the scene from eight processes on, see below: the buffers of a frame are in use from its
+    # launch to the end of its collective, one frame longer than its scene copy)
+    copies = 1 if not distributed else int(os.environ.get("CRT_BENCH_COPIES", "3" if world >= 8 else "2"))
+    depth = copies + 1 if distributed else 1
+    # With more than one process consecutive frames also render on two or three device copies of the scene (each
+    # has its own stream and scratch): a rank's share of the frame is short, and the last long paths of one frame
+    # then overlap the start of the next instead of leaving the GPU half empty (one rank's eighth of the Cornell
+    # frame: 1.38 ms per frame one at a time, 1.26 with two copies, 1.19 with three; a quarter: 2.29 / 2.11 / 2.09).
+    # A single-GPU run keeps one frame at a time, so that the kernel durations behind the roofline are those of a
+    # kernel that has the GPU to itself.
     scenes = [sc]
-    if distributed:
-        second = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
+    for _ in range(copies - 1):
+        other = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
         if args.spp > 0:
-            second.set_render(samples=args.spp)
-        second.upload()
-        scenes.append(second)
+            other.set_render(samples=args.spp)
+        other.upload()
+        scenes.append(other)
     band_rows = multi_gpu.BAND_ROWS
     if sharding == "tiles":
         own_rows = crt.band_row_count(H, band_rows, rank, world)

@@ -270,7 +270,7 @@ struct SceneLds {
     __device__ __forceinline__ const float* xform(int x) const { return xforms + x * kXformFloats; }
 };
 
-// Per-lane traversal stack.  The first kLdsStackMax entries of lane l live in LDS at
+// Per-lane traversal stack.  The first `lds_entries` entries (7 or 11) of lane l live in LDS at
 // base[e * stride + l] (conflict-free); a walk that goes deeper continues in a per-thread slice
 // of global memory (spill[(e - lds_entries) * spill_stride]), so that LDS use - and with it the
 // number of resident waves - does not grow with the depth of the tree.

@@ -278,7 +278,7 @@ def test_fast_reciprocal_variant_is_bit_identical(crt):
 
 
 def test_million_triangle_scene_bit_exact(crt, oracle, tmp_path):
-    """mesh1m.yaml (1 002 536 objects, BVH deeper than the 16 LDS stack entries, so the walks use
+    """mesh1m.yaml (1 002 536 objects, BVH deeper than the 11 LDS stack entries, so the walks use
     the global part of their stacks): hits and passes equal to the oracle's, sample by sample."""
     import os
     import subprocess
