@@ -297,7 +297,7 @@ struct LaneStack {
     // empty stack reads ("no node left": the pop needs no test for the empty stack); entry e of this lane is at
     // base[e * stride] with base in row 1.
     __device__ __forceinline__ void attach(int* lds_rows, int rows, int threads, int thread) {
-        lds_rows[thread] = -1;
+        if (rows > 0) lds_rows[thread] = -1;                       // (no rows: a kernel variant that never walks a tree)
         base = (LdsIntPtr)(lds_rows + threads + thread);
         stride = threads;
         lds_entries = rows - 1;
