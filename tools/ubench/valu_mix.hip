@@ -76,6 +76,8 @@ int main() {
     RUN(6, ~0ull, "all lanes") RUN(7, ~0ull, "all lanes") RUN(8, ~0ull, "all lanes") RUN(9, ~0ull, "all lanes") RUN(10, ~0ull, "all lanes") RUN(11, ~0ull, "all lanes")
     RUN(12, ~0ull, "all lanes") RUN(13, ~0ull, "all lanes") RUN(14, ~0ull, "all lanes") RUN(15, ~0ull, "all lanes") RUN(16, ~0ull, "all lanes") RUN(17, ~0ull, "all lanes")
     RUN(0, 0xffffffffull, "lanes 0-31") RUN(0, 0xffffull, "lanes 0-15") RUN(0, 0x1111111111111111ull, "every 4th lane") RUN(0, 1ull, "one lane") RUN(0, 0x0001000100010001ull, "one lane per quarter")
+    RUN(0, 0x3ull, "two lanes") RUN(0, 0xfull, "lanes 0-3") RUN(0, 0xffull, "lanes 0-7") RUN(0, 0x0101010101010101ull, "every 8th lane") RUN(0, 0x00010001ull, "lanes 0 and 16") RUN(0, 0x100000001ull, "lanes 0 and 32")
+    RUN(0, 0x1ffull, "9 lanes") RUN(0, 0x3ffull, "10 lanes") RUN(0, 0xfffull, "12 lanes") RUN(0, 0x3fffull, "14 lanes") RUN(0, 0x7fffull, "15 lanes") RUN(0, 0x1ffffull, "17 lanes") RUN(0, 0x00ff00ffull, "8 + 8 lanes in two quarters") RUN(0, 0x000f000f000f000full, "4 lanes in each quarter")
     RUN(6, 0xffffffffull, "lanes 0-31") RUN(6, 0xffffull, "lanes 0-15") RUN(6, 0x1111111111111111ull, "every 4th lane") RUN(6, 1ull, "one lane") RUN(6, 0x0001000100010001ull, "one lane per quarter")
     return 0;
 }
