@@ -439,13 +439,19 @@ __device__ __forceinline__ bool sphere_test(V3 o, V3 d, float time, V3 c0, V3 cd
 // open one (:287-289).  With `rank` = position of a primitive in that order, "tested later wins
 // a tie if it is a triangle, never if it is a sphere" reproduces the reference's choice in any
 // test order.  best.obj holds the rank of the best candidate so far.
+// One refinement for the tree walks, which may meet the later-ranked of two tied candidates first: the
+// reference would have met the earlier one first, shrunk the ray interval to t, and then tested the later one
+// only if its box is still hit on [tmin, t] (bvh.cuh:398-411) - which fails when the hit lies, by rounding,
+// just before the computed entry distance of its own box (a ray through an edge that lies in a box face).
+// `lo` = box entry distance of the candidate, `best_lo` = that of the best so far; the flat mode passes -inf.
 // ALL_TRI: the scene holds nothing but triangles, so the best candidate so far is one and `best_tri` is
 // neither read nor written (a flag less to carry round the loops).
 template <bool ALL_TRI = false>
-__device__ __forceinline__ void consider(Hit& best, bool& best_tri, bool ok, float t, int rank, bool is_tri, float bu, float bv) {
-    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? (ALL_TRI || is_tri) : (ALL_TRI ? false : !best_tri));
+__device__ __forceinline__ void consider(Hit& best, bool& best_tri, float& best_lo, bool ok, float t, float lo, int rank, bool is_tri, float bu, float bv) {
+    const bool best_would_be_culled = best_lo > t;             // (only read when t == best.t)
+    const bool win_tie = best.obj < 0 ? true : ((rank > best.obj) ? (ALL_TRI || is_tri) : ((ALL_TRI ? false : !best_tri) || best_would_be_culled));
     if (ok && (t < best.t || (t == best.t && win_tie))) {
-        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv;
+        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_lo = lo;
         if (!ALL_TRI) best_tri = is_tri;
     }
 }
@@ -477,10 +483,11 @@ struct TreeState {
     Hit best;                           // best.obj = visiting rank while walking
     int best_obj;                       // object index of the best candidate
     bool best_tri;
+    float best_lo;                      // entry distance of the best candidate's box (exact ties, see consider())
     __device__ __forceinline__ void begin(float tmax, int root_entry) {
         node = root_entry; sp = 0; leaf_mask = 0;
         best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
-        best_obj = -1; best_tri = false;
+        best_obj = -1; best_tri = false; best_lo = -INFINITY;
     }
     __device__ __forceinline__ Hit result() const { Hit h = best; h.obj = best_obj; return h; }
 };
@@ -491,7 +498,7 @@ struct TreeState {
 __device__ __forceinline__ void keep_loaded(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 
 template <int FAST, int FEAT = kFeatAll, class Mem>
-__device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, float tmin, TreeState& ts) {
+__device__ __forceinline__ void tree_prim(const Mem& S, int obj, float lo, const Ray& r, float tmin, TreeState& ts) {
     float4 q0 = S.prim(obj, 0), q1 = S.prim(obj, 1), q2 = S.prim(obj, 2);
     keep_loaded(q0); keep_loaded(q1); keep_loaded(q2);
     const int xf = __float_as_int(q2.y), type = __float_as_int(q2.z), rank = __float_as_int(q2.w);
@@ -501,13 +508,13 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, const Ray& r, f
     if (!(FEAT & kFeatSphere) || type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
         const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, FAST, t, bu, bv);
-        consider<!(FEAT & kFeatSphere)>(ts.best, ts.best_tri, ok, t, rank, true, bu, bv);
+        consider<!(FEAT & kFeatSphere)>(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, true, bu, bv);
     } else {
         // the root the reference would take does not depend on the interval's upper end: the
         // near root if it is beyond tmin, else the far one (hittable.cuh:283-289)
         float t = 0.0f;
         const bool ok = sphere_test<FAST>(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, INFINITY, t);
-        consider(ts.best, ts.best_tri, ok, t, rank, false, 0.0f, 0.0f);
+        consider(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, false, 0.0f, 0.0f);
     }
     if (ts.best.obj != before) ts.best_obj = obj;
 }
@@ -635,7 +642,7 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 // an earlier candidate may have shrunk the interval below this box's entry
                 if (!(ts.best.t < lo)) {
                     CRT_PROF(kProfPrim);
-                    tree_prim<FAST, FEAT>(S, code, r, tmin, ts);
+                    tree_prim<FAST, FEAT>(S, code, lo, r, tmin, ts);
                 }
             }
             stepping = lanes_where(can_step(next, leaf_mask));
@@ -906,6 +913,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     Hit best;
     best.t = tmax; best.obj = -1; best.bu = 0.0f; best.bv = 0.0f;
     bool best_tri = false;
+    float no_lo = -INFINITY;                                   // (no box entry distances in this mode: consider())
     CRT_CLOCK(clk, kSecPrim, cand_lo);
     while (cand_lo | cand_hi) {
         CRT_PROF(kProfPrim);
@@ -937,12 +945,12 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
         if (!(FEAT & kFeatSphere) || is_tri) {
             const TriEval A = tri_eval(o, d, v3(q0.z, q0.w, q1.x), v3(q1.y, q1.z, q1.w), v3(q2.x, q2.y, q2.z), tmin, tmax, FAST);
-            consider<!(FEAT & kFeatSphere)>(best, best_tri, A.ok, A.t, rank_a, true, A.u, A.v);
+            consider<!(FEAT & kFeatSphere)>(best, best_tri, no_lo, A.ok, A.t, -INFINITY, rank_a, true, A.u, A.v);
             float bx = q2.w;
             asm volatile("" : "+v"(bx) : : "memory");              // keeps the two loads below behind triangle A
             const float4 q3 = rec[3], q4 = rec[4];
             const TriEval B = tri_eval(o, d, v3(bx, q3.x, q3.y), v3(q3.z, q3.w, q4.x), v3(q4.y, q4.z, q4.w), tmin, tmax, FAST);
-            consider<!(FEAT & kFeatSphere)>(best, best_tri, B.ok && has_b, B.t, rank_b, true, B.u, B.v);
+            consider<!(FEAT & kFeatSphere)>(best, best_tri, no_lo, B.ok && has_b, B.t, -INFINITY, rank_b, true, B.u, B.v);
         } else {
             // sphere slot: {c0.xyz, radius} {cd.xyz, 0}.  The root the reference would take does not
             // depend on the upper bound: the near root if it is beyond tmin, else the far one.
@@ -957,7 +965,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             float r1 = FAST ? quotient(-h - sq, a, ra) : (-h - sq) / a, r2 = FAST ? quotient(-h + sq, a, ra) : (-h + sq) / a;
             float root = (tmin < r1 && r1 < tmax) ? r1 : r2;
             bool ok = !(disc < 0.0f) && (tmin < root && root < tmax);
-            consider(best, best_tri, ok, root, rank_a, false, 0.0f, 0.0f);
+            consider(best, best_tri, no_lo, ok, root, -INFINITY, rank_a, false, 0.0f, 0.0f);
         }
     }
     return best;
