@@ -108,7 +108,8 @@ def cpu_baseline(scene_file, width, height, spp_all, threads_all):
     full-size image at a reduced sample count): one thread and `threads_all` OpenMP threads, plus
     the reference's own CPU-sized case (orthographic 256x256, 8 spp, 10 bounces)."""
     name = os.path.basename(scene_file)
-    v1, rays1, dt1 = oracle_rate(scene_file, width, height, 1, 0, 1)
+    spp_1 = max(1, min(4, spp_all))
+    v1, rays1, dt1 = oracle_rate(scene_file, width, height, spp_1, 0, 1)
     va, raysa, dta = oracle_rate(scene_file, width, height, spp_all, 0, threads_all)
     ortho = os.path.join(ROOT, "scenes", "orthographic.yaml")
     o1, orays, odt1 = oracle_rate(ortho, 256, 256, 8, 10, 1)
@@ -116,7 +117,7 @@ def cpu_baseline(scene_file, width, height, spp_all, threads_all):
     return {"value": round(va, 3), "unit": "Mrays/s", "cores": threads_all, "kind": "port",
             "threads_1": round(v1, 3), "threads_all": round(va, 3),
             "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
-            "sample": f"{name} {width}x{height}, all bounces: 1 thread on 1 of the spp ({rays1} rays in {dt1:.2f} s), "
+            "sample": f"{name} {width}x{height}, all bounces: 1 thread on {spp_1} of the spp ({rays1} rays in {dt1:.2f} s), "
                       f"{threads_all} OpenMP threads (this job's CPU share of the node's {os.cpu_count()} logical CPUs) on "
                       f"{spp_all} of the spp ({raysa} rays in {dta:.2f} s)",
             "config1_orthographic_256x256_8spp_10bounces": {"threads_1": round(o1, 3), "threads_all": round(oa, 3), "rays": orays,
@@ -133,7 +134,7 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = the scene's frame divided over the GPUs (default), weak = the scene's spp per GPU")
     ap.add_argument("--sharding", choices=("auto", "samples", "tiles"), default="auto", help="how a strong-scaling frame is divided")
-    ap.add_argument("--cpu-spp", type=int, default=10, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=50, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
