@@ -118,10 +118,10 @@ def random_scene(seed, count):
 
 
 CASES = [(seed, count) for seed, count in zip(range(101, 117), (1, 3, 6, 6, 9, 14, 20, 20, 33, 48, 75, 75, 120, 260, 700, 700))]
-# CRT_FUZZ_EXTRA=n adds n more scenes, CRT_FUZZ_SCALE=k renders them k times as wide and high
-# (a longer hunt than the default run needs)
+# CRT_FUZZ_EXTRA=n adds n more scenes (seeds CRT_FUZZ_BASE + k, default base 1000), CRT_FUZZ_SCALE=k renders
+# them k times as wide and high (a longer hunt than the default run needs)
 _COUNTS = (2, 2, 5, 8, 8, 12, 18, 18, 27, 40, 40, 60, 90, 90, 150, 300, 300, 500, 500)
-CASES += [(1000 + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.get("CRT_FUZZ_EXTRA", "0")))]
+CASES += [(int(os.environ.get("CRT_FUZZ_BASE", "1000")) + k, _COUNTS[k % len(_COUNTS)]) for k in range(int(os.environ.get("CRT_FUZZ_EXTRA", "0")))]
 
 
 @pytest.fixture(scope="module")
