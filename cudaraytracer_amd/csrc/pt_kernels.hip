@@ -135,16 +135,25 @@ __device__ __forceinline__ FlatLds stage_flat_in_lds(const FlatView& F, const fl
     return L;
 }
 
-// Adds a finished path's contribution to the tile sums.  Adding an exact zero cannot change a
-// sum (sums start at +0 and x + 0 == x for every x including NaN), so zeros are skipped: most
-// contributions of short paths are zero (black environment, non-emitting first hit).
-template <int TP>
-__device__ __forceinline__ void acc_add(float* acc, int plane, int pix, float v) {
-    if (v != 0.0f) atomicAdd(&acc[plane * TP + pix], v);
+// Adds a finished path's contribution to the tile sums of its wave: a plain read-add-write, valid only
+// while no other lane of the wave adds to the same pixel in the same instruction (render_fused's
+// `accumulate` sees to that).  An LDS float atomic (ds_add_f32) takes about three cycles PER LANE on
+// gfx950 whatever the addresses are (tools/ubench/lds_atomic.hip: 80 ns for a 64-lane instruction, the
+// LDS pipe of the CU is busy all that time); the plain form is three full-rate instructions.
+// Sums of a wave: [plane][2 open items][tile pixel]; `slot` = item buffer * TP + pixel.
+// ATOMIC: the atomic form after all, zeros skipped (adding an exact zero cannot change a sum that starts at
+// +0, so either form gives the same bits).  The flat kernel for basic scenes is bound by instruction issue
+// at six waves per SIMD, not by the LDS pipe, and is 1 % faster with it (Cornell 7.87 against 7.96 ms); every
+// other variant is faster with the plain form (orthographic 1.65 -> 1.49 ms, the 976-triangle scene 9.55 ->
+// 9.10, materials 13.9 -> 13.4).
+template <int TP, bool ATOMIC>
+__device__ __forceinline__ void acc_add(float* acc, int plane, int slot, float v) {
+    if (ATOMIC) { if (v != 0.0f) atomicAdd(&acc[plane * 2 * TP + slot], v); }
+    else acc[plane * 2 * TP + slot] += v;
 }
-template <int TP>
-__device__ __forceinline__ void acc_add3(float* acc, int plane, int pix, V3 v) {
-    acc_add<TP>(acc, plane, pix, v.x); acc_add<TP>(acc, plane + 1, pix, v.y); acc_add<TP>(acc, plane + 2, pix, v.z);
+template <int TP, bool ATOMIC>
+__device__ __forceinline__ void acc_add3(float* acc, int plane, int slot, V3 v) {
+    acc_add<TP, ATOMIC>(acc, plane, slot, v.x); acc_add<TP, ATOMIC>(acc, plane + 1, slot, v.y); acc_add<TP, ATOMIC>(acc, plane + 2, slot, v.z);
 }
 
 // LDS carve-up of a block: [pass sums: waves x 2 x 14 x 32 floats][sampler scratch][stacks: STACK x 256 ints][scene copy]
@@ -152,9 +161,10 @@ constexpr int kCoopWordsPerWave = 192;          // coop_sphere_sample: published
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
 constexpr int kItemWords = 8;                    // per wave: the cold part of its work items (tile position, first sample, ...)
+constexpr int kTagWords = 64;                    // per wave: which lane adds to a pixel of the two open items this round
 constexpr int kParkWords = 3;                    // flat mode: per-lane path state kept in LDS
 static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
-constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave + kItemWords) * 4 + kCamWords * 4 / kWaves; }
+constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave + kItemWords + kTagWords) * 4 + kCamWords * 4 / kWaves; }
 
 // One work item of a wave: the 8x4 pixel tile `tile`, samples [s0, s0 + items/32).
 struct WorkItem {
@@ -187,7 +197,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     constexpr bool kItemInLds = MODE == kModeFlat;
     typedef volatile int __attribute__((address_space(3))) * LdsVolatileIntPtr;
     LdsVolatileIntPtr item_mem = (LdsVolatileIntPtr)(reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords) + (threadIdx.x >> 6) * kItemWords);
-    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * kItemWords);
+    static_assert(2 * kTilePixels <= kTagWords, "one tag word per pixel of the two open items");
+    int* tag = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * kItemWords) + (threadIdx.x >> 6) * kTagWords;
+    int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * (kItemWords + kTagWords));
     float* entry_mem = reinterpret_cast<float*>(stack_mem + STACK * kBlock);      // tree modes: 4 slot codes + 4 box entry distances per lane
     // Flat mode: the albedo a path shows in the albedo pass is found at its first hit and only added when
     // the path ends (an exhausted path shows black, render.cuh:96-97); it waits in LDS, three words per
@@ -256,14 +268,14 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     };
     // tile sums of one finished item -> HBM (lane = pixel of the tile), buffer cleared for the next item
     auto flush = [&](int buffer, int tile, int chunk) {
-        float* sums = acc + buffer * kAccFloatsPerTile;
+        float* sums = acc + buffer * kTilePixels;
         float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * kTilePixels + lane;
         const size_t ps = A.pix_padded;
         if (lane < kTilePixels) {
 #pragma unroll
             for (int k = 0; k < kPasses; k++) {
-                out[k * ps] = sums[k * kTilePixels + lane];
-                sums[k * kTilePixels + lane] = 0.0f;
+                out[k * ps] = sums[k * 2 * kTilePixels + lane];
+                sums[k * 2 * kTilePixels + lane] = 0.0f;
             }
         }
     };
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
 
     unsigned int rays = 0;
     bool alive = false;
-    int pixoff = 0;                                               // buffer * 448 + pixel of the tile: where this lane's path adds its results
+    int pixoff = 0;                                               // item buffer * tile pixels + pixel of the tile: where this lane's path adds its results
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);       // (pend_albedo: tree modes; flat mode keeps it in `park`)
@@ -294,6 +306,34 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     ts.begin(INFINITY, sc.root_entry);
     bool walking = false;
 
+    // Runs `adds` (plain read-add-writes to this lane's pixel) for every lane that calls, lanes that share a
+    // pixel one after the other: each lane writes its number to the pixel's tag word, the lane whose number
+    // stands there adds, the others try again.  One round unless two samples of a pixel finish in the same
+    // instruction.  (LDS executes a wave's instructions in order; the fences only keep the compiler from moving
+    // or caching the accesses.)
+    constexpr bool kAtomicSums = MODE == kModeFlat && FEAT == kFeatBasicXform;
+    auto accumulate = [&](auto&& adds) {
+        if constexpr (kAtomicSums) { adds(); return; }
+        bool todo = true;
+        while (true) {
+            if (todo) tag[pixoff] = lane;
+            wave_lds_sync();
+            const bool win = todo && tag[pixoff] == lane;
+            if (win) { adds(); todo = false; }
+            wave_lds_sync();
+            if (!lanes_where(todo)) break;
+        }
+    };
+
+    // Flat mode: the lanes at their first hit are exactly the ones that took a new path at the top of this
+    // iteration, consecutive samples of one item; no two of them share a pixel unless more than a tile's
+    // worth of paths started at once.  Then they add without asking.
+    bool first_hits_unique = false;
+    auto accumulate_first = [&](auto&& adds) {
+        if (kAtomicSums || (MODE == kModeFlat && first_hits_unique)) adds();
+        else accumulate(adds);
+    };
+
     SectionClock clk;
     clk.start();
     while (true) {
@@ -310,8 +350,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         }
         // the drained item is complete when none of its paths is alive any more
         if (draining) {
-            const int drain_base = (fill_buffer ^ 1) * kAccFloatsPerTile;
-            const bool mine = alive && ((pixoff >= kAccFloatsPerTile) == (drain_base != 0));
+            const bool mine = alive && ((pixoff >= kTilePixels) == ((fill_buffer ^ 1) != 0));
             if (!lanes_where(mine)) {
                 if constexpr (kItemInLds) flush(fill_buffer ^ 1, item_mem[6], item_mem[7]);
                 else flush(fill_buffer ^ 1, drain_tile, drain_chunk);
@@ -329,8 +368,10 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             fill_buffer ^= 1;
             fill = fetch();
         }
+        if constexpr (MODE == kModeFlat && !kAtomicSums) first_hits_unique = true;    // (no new paths this iteration: nobody is at a first hit)
         if (fill.next < fill.total) {                             // wave-uniform
             const unsigned long long free_mask = lanes_where(!alive);
+            if constexpr (MODE == kModeFlat && !kAtomicSums) first_hits_unique = __builtin_popcountll(free_mask) <= kTilePixels;
             if (!alive) {
                 CRT_PROF(kProfRegen);
                 const int item = fill.next + __builtin_popcountll(free_mask & ((1ull << lane) - 1ull));
@@ -340,7 +381,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     const int sample = s0 + item / kTilePixels + 1;       // sample numbers are 1-based (render.cuh:128)
                     const int pi = tx * kTileW + (pix & 7), pj = ty * kTileH + (pix >> 3);
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
-                        pixoff = fill_buffer * kAccFloatsPerTile + pix;
+                        pixoff = fill_buffer * kTilePixels + pix;
                         rng.init(pj * sc.width + pi, sample);
                         ray = camera_ray<FEAT>(*lds_cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
@@ -406,9 +447,12 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                         set_pending_albedo(attenuation);
                         V3 n = sf.unit_normal;
                         if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
-                        acc_add3<kTilePixels>(acc, 9, pixoff, n);
-                        acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
-                        acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
+                        const float depth = h.t * length(ray.d);
+                        accumulate_first([&]() {
+                            acc_add3<kTilePixels, kAtomicSums>(acc, 9, pixoff, n);
+                            acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, depth);
+                            acc_add<kTilePixels, kAtomicSums>(acc, 13, pixoff, 1.0f);
+                        });
                     }
                     throughput = throughput * attenuation;
                     ray = next;
@@ -418,29 +462,36 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                 } else {                                             // render.cuh:64-74
                     V3 emitted = emit<FEAT>(sc, sf);
                     V3 c = throughput * emitted;
-                    acc_add3<kTilePixels>(acc, 0, pixoff, c);
                     V3 alb = emitted;
                     if (bounces != 0) alb = pending_albedo();
+                    V3 n = v3(0.0f, 0.0f, 0.0f);
+                    float depth = 0.0f;
                     if (bounces == 0) {
-                        V3 n = sf.unit_normal;
+                        n = sf.unit_normal;
                         if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
-                        acc_add3<kTilePixels>(acc, 6, pixoff, emitted);
-                        acc_add3<kTilePixels>(acc, 9, pixoff, n);
-                        acc_add<kTilePixels>(acc, 12, pixoff, h.t * length(ray.d));
-                        acc_add<kTilePixels>(acc, 13, pixoff, 1.0f);
+                        depth = h.t * length(ray.d);
                     }
-                    acc_add3<kTilePixels>(acc, 3, pixoff, alb);
+                    accumulate([&]() {
+                        acc_add3<kTilePixels, kAtomicSums>(acc, 0, pixoff, c);
+                        if (bounces == 0) {
+                            acc_add3<kTilePixels, kAtomicSums>(acc, 6, pixoff, emitted);
+                            acc_add3<kTilePixels, kAtomicSums>(acc, 9, pixoff, n);
+                            acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, depth);
+                            acc_add<kTilePixels, kAtomicSums>(acc, 13, pixoff, 1.0f);
+                        }
+                        acc_add3<kTilePixels, kAtomicSums>(acc, 3, pixoff, alb);
+                    });
                     alive = false;
                 }
             } else {                                                 // render.cuh:76-91
                 V3 c = throughput * environment<FEAT, FAST>(sc, ray.d);
-                acc_add3<kTilePixels>(acc, 0, pixoff, c);
                 V3 alb = c;
                 if (bounces != 0) alb = pending_albedo();
-                if (bounces == 0) {
-                    atomicAdd(&acc[12 * kTilePixels + pixoff], __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
-                }
-                acc_add3<kTilePixels>(acc, 3, pixoff, alb);
+                accumulate([&]() {
+                    acc_add3<kTilePixels, kAtomicSums>(acc, 0, pixoff, c);
+                    if (bounces == 0) acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
+                    acc_add3<kTilePixels, kAtomicSums>(acc, 3, pixoff, alb);
+                });
                 alive = false;
             }
         }
