@@ -228,3 +228,34 @@ def test_deterministic_option_makes_bulk_renders_bit_reproducible(crt):
         c = images[0][0]
         np.testing.assert_allclose(c[k], a[k], rtol=2e-5, atol=1e-6, equal_nan=True, err_msg=k)
         np.testing.assert_allclose(images[0][1][k], a[k], rtol=2e-5, atol=1e-6, equal_nan=True, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,mode", [("orthographic.yaml", 0), ("materials.yaml", 0), ("obj.yaml", 1), ("features_small.yaml", 2),
+                                        ("cornell_box.yaml", 0)])
+def test_many_samples_of_a_pixel_in_one_wave_lose_no_addition(crt, scene, mode):
+    """Tile sums are added without atomics; lanes that hold samples of the same pixel take turns
+    (a tag word per pixel).  With one chunk for all samples every work item holds 48 samples of
+    each of its 32 pixels, so a wave always carries several samples of a pixel.  A lost or doubled
+    addition would change a pixel by about 1/48 of a sample's value; against the render with one
+    sample per chunk (no two samples of a pixel ever in flight together) only the summation order
+    may differ."""
+    from cudaraytracer_amd import api
+    images, rays = {}, {}
+    for deterministic in (1, 0):
+        sc = crt.load_scene(scene_path(scene), base_dir=scene_path(""))
+        sc.set_render(96, 64, samples=48)
+        if deterministic:
+            sc.set_options(deterministic=1)
+        else:
+            sc.set_options(work_items=1)                 # one chunk: 48 samples per pixel and item
+        sc.set_mode(mode)
+        buf = crt.create_buffer(sc)
+        crt.render(sc, buf)
+        images[deterministic], rays[deterministic] = buf.download(), api.last_ray_count
+        buf.close()
+        sc.close()
+    assert rays[0] == rays[1] and rays[0] > 0
+    for k in oracle_lib.PASSES:
+        assert np.array_equal(np.isnan(images[0][k]), np.isnan(images[1][k])), k
+        np.testing.assert_allclose(images[0][k], images[1][k], rtol=3e-5, atol=2e-6, equal_nan=True, err_msg=k)
