@@ -3,7 +3,13 @@
 (1000x1000, 50 spp, 15 bounces) on N MI355X of one node.
 
   python bench.py --gpus N --steps K --warmup W [--scene S] [--scaling strong|weak] [--sharding auto|samples|tiles]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one process per GPU.  Started under a launcher (python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) this process is one rank.  Started plainly (no RANK in the environment) with
+--gpus N > 1 it is the PARENT: before anything touches a GPU it checks that N devices are visible,
+starts the N ranks as child processes under torch.distributed.run, relays rank 0's JSON line and
+exits with the children's status.  A launcher's WORLD_SIZE that differs from --gpus is an error.
 
 A step = one full render of the scene's frame.  With N GPUs the default is STRONG scaling: the
 same frame (the scene's own sample count) is divided over the ranks, either by image tiles (row
@@ -18,12 +24,15 @@ timed region; the timed region contains the render kernels, the resolve kernel a
 A ray = one closest-hit query = one call of bvh4_hit at the reference's render.cuh:47; the
 kernels count them on the device.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 on the headline scene the line also carries, under
+"configs", the other BASELINE configurations (orthographic, obj, materials, materials + HDR
+environment, 1 M triangles) measured a few frames each after the timed headline region.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -59,14 +68,20 @@ def flops_per_ray(scene):
     return None if c is None else 24.0 * c[1] + 84.0 * c[2] + 60.0 * c[3] + 100.0
 
 
+TRAFFIC_CAVEAT = ("an estimate: FETCH_SIZE counts a 128-byte request as 64 bytes on gfx950, hence the factor 2, which is "
+                  "calibrated on 16-byte-per-lane streaming reads only and uncalibrated for gather-type accesses")
+
+
 def measured_traffic(scene):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate
-    rocprofv3 --pmc runs of FETCH_SIZE and WRITE_SIZE); None if this scene was not measured."""
+    """(HBM bytes per launch of the dominant kernel, how they were obtained) from the committed PMC
+    passes (separate rocprofv3 --pmc runs of FETCH_SIZE and WRITE_SIZE); (None, None) if this scene
+    was not measured."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[scene]["bytes_per_launch"]
+            rec = json.load(f)[scene]
+        return rec["bytes_per_launch"], rec["source"] + "; " + TRAFFIC_CAVEAT
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def ensure_assets(scene):
@@ -124,6 +139,128 @@ def cpu_baseline(scene_file, width, height, spp_all, threads_all):
                                                             "seconds_1": round(odt1, 3), "seconds_all": round(odta, 3)}}
 
 
+def roofline_block(scene, rays_per_launch, kernel_ms, resolve_ms, with_traffic):
+    """The `roofline` object of the result line for one scene's dominant kernel (render_fused)."""
+    flops = flops_per_ray(scene)
+    if not flops or kernel_ms <= 0.0:
+        return None
+    counts = REFERENCE_COUNTS[scene]
+    achieved = rays_per_launch * flops / (kernel_ms * 1e-3) / 1e12
+    traffic, source = measured_traffic(scene) if with_traffic else (None, None)
+    hbm_achieved = None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9
+    return {
+        "bound": "valu", "kernel": "render_fused", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+        "kernel_ms": round(kernel_ms, 4), "resolve_ms": round(resolve_ms, 4),
+        "rays_per_launch": int(rays_per_launch),
+        "flops_per_ray": round(flops, 1),
+        "flops_model": "reference-algorithm flops: 24*N_box + 84*N_prim + 60*N_accept + 100 with the counts of the "
+                       "reference's own traversal (oracle, reduced image size), not the instructions these kernels issue",
+        "reference_counts_per_ray": {"node_pops": counts[0], "box_tests": counts[1], "prim_tests": counts[2], "accepts": counts[3]},
+        "hbm": {"achieved": None if hbm_achieved is None else round(hbm_achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": None if hbm_achieved is None else round(hbm_achieved / PEAK_HBM_GBS, 5),
+                "source": source,
+                "modelled_wavefront_equivalent": {
+                    "bytes_per_ray": STATE_BYTES_PER_RAY,
+                    "GB/s": round(rays_per_launch * STATE_BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9, 1),
+                    "note": "state a multi-kernel wavefront tracer would move through HBM per ray; the fused kernel keeps it in registers",
+                    "scene_bytes_per_ray_reference_walk": round(128.0 * counts[0] + 48.0 * counts[2], 1)}}}
+
+
+# The BASELINE configurations besides the headline one: (scene file, timed frames, warmup frames).
+OTHER_CONFIGS = (("orthographic.yaml", 10, 2), ("obj.yaml", 5, 1), ("materials.yaml", 5, 1),
+                 ("materials_hdr.yaml", 5, 1), ("mesh1m.yaml", 2, 1))
+
+
+def measure_config(crt, torch, scene_name, steps, warmup):
+    """One BASELINE configuration on the current GPU, one frame at a time: whole-step Mrays/s over
+    `steps` frames (wall clock around launch + kernel + resolve, inputs resident), the render
+    kernel's mean HIP-event duration and the roofline fractions that follow from it."""
+    ensure_assets(scene_name)
+    scene_file = os.path.join(ROOT, "scenes", scene_name)
+    sc = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
+    ri = sc.render_info
+    W, H, spp, bounces = ri.image_width, ri.image_height, ri.samples_per_pixel, ri.max_bounces
+    sc.upload()
+    buf = crt.create_buffer(sc)
+    lib = crt.lib()
+
+    def frames(n):
+        rays, trace_ms, resolve_ms = 0, 0.0, 0.0
+        for _ in range(n):
+            crt.render_launch(sc, buf, 0, spp)
+            _, r = crt.render_finish(sc)
+            tr, rs = C.c_float(0), C.c_float(0)
+            lib.crt_render_timings(sc.get_device_scene(), C.byref(tr), C.byref(rs))
+            rays += r
+            trace_ms += tr.value
+            resolve_ms += rs.value
+        return rays, trace_ms, resolve_ms
+
+    frames(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays, trace_ms, resolve_ms = frames(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    describe = sc.describe()
+    buf.close()
+    sc.close()
+    roof = roofline_block(scene_name, rays / steps, trace_ms / steps, resolve_ms / steps, True)
+    return {"workload": f"{scene_name} {W}x{H}, {spp} spp, {bounces} bounces", "value": round(rays / elapsed / 1e6, 1),
+            "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "rays_per_step": rays // steps, "kernel_ms": round(trace_ms / steps, 4), "resolve_ms": round(resolve_ms / steps, 4),
+            "frac": None if roof is None else roof["frac"], "achieved_tflops": None if roof is None else roof["achieved"],
+            "flops_per_ray": None if roof is None else roof["flops_per_ray"],
+            "hbm": None if roof is None else {k: roof["hbm"][k] for k in ("achieved", "peak", "unit", "frac")},
+            "traffic": None if roof is None else roof["traffic"], "kernel_variant": describe}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """Devices this process could use.  torch.cuda.device_count() reads the driver's device list
+    without creating a HIP context, so the parent stays free to start children afterwards."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(n, argv, script=None, device_count=None, timeout=None):
+    """The parent of an N-rank run: checks that `n` devices are visible, starts the ranks as
+    children under torch.distributed.run (fresh processes: nothing here has touched a GPU), relays
+    rank 0's JSON line to stdout and returns the exit status (non-zero if a rank failed, printed no
+    result, or the devices are missing).  `script` / `device_count` exist for tests: a stand-in
+    child program and a stand-in for the number of visible devices."""
+    have = visible_gpus() if device_count is None else device_count
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have}; nothing was measured", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        done = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n} ranks did not finish within {timeout} s", file=sys.stderr)
+        return 3
+    lines = [ln for ln in done.stdout.decode("utf-8", "replace").splitlines() if ln.lstrip().startswith("{")]
+    if done.returncode != 0:
+        print(f"bench.py: a rank failed (launcher exit status {done.returncode}); no result reported", file=sys.stderr)
+        return done.returncode
+    if not lines:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 4
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +273,21 @@ def main():
     ap.add_argument("--sharding", choices=("auto", "samples", "tiles"), default="auto", help="how a strong-scaling frame is divided")
     ap.add_argument("--cpu-spp", type=int, default=50, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-configs", action="store_true", help="N = 1, headline scene: skip the other BASELINE configurations")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    launched = "RANK" in os.environ
+    if not launched and args.gpus > 1:
+        # the parent of an N-rank run: it never touches a GPU itself
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # every rank sees the same two numbers and leaves together, before any collective
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; nothing was measured")
 
     # stdout carries exactly one line, the result; anything native libraries print on the way
     # (RCCL's version banner, for one) goes to stderr instead
@@ -149,18 +300,15 @@ def main():
     import cudaraytracer_amd as crt
     from cudaraytracer_amd import multi_gpu
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     crt.set_device(local_rank)
     # under torch.distributed.run (RANK is set) the collective path runs even with one rank, so a
     # single-GPU box can rehearse exactly what the N-GPU launch does
-    distributed = world > 1 or "RANK" in os.environ
+    distributed = launched
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -178,9 +326,12 @@ def main():
     W, H, spp, bounces = ri.image_width, ri.image_height, ri.samples_per_pixel, ri.max_bounces
     sc.upload()
     lib = crt.lib()
-    dev = sc.get_device_scene()
 
-    # ---- how the frame is divided
+    # ---- how the frame is divided.  Whether a split gives every rank work depends only on the
+    # frame and the world size, so every rank decides alike and they all stop together if it does
+    # not (a rank that left on its own would leave the others waiting in the first collective).
+    single_gpu_ms = None
+    predicted = None
     if not distributed:
         sharding, first, count, total_spp = "single", 0, spp, spp
     elif args.scaling == "weak":
@@ -188,13 +339,28 @@ def main():
         first, count = multi_gpu.rank_sample_range(rank, world, spp)
     else:
         total_spp = spp
-        sharding = args.sharding if args.sharding != "auto" else multi_gpu.choose_sharding(W, H, spp, world)
-        if sharding == "samples":
-            first, count = multi_gpu.split_samples(spp, world)[rank]
-            if count == 0:
-                raise SystemExit(f"bench.py: {spp} samples cannot be divided over {world} GPUs; use --sharding tiles")
-        else:
-            first, count = 0, spp
+        try:
+            if args.sharding != "auto":
+                multi_gpu.check_sharding(args.sharding, H, spp, world)
+                sharding = args.sharding
+            elif world == 1:
+                sharding = "samples"
+            else:
+                multi_gpu.choose_sharding(W, H, spp, world)      # raises if neither split is possible
+                # the cost model wants this scene's frame time on one GPU: render the whole frame once
+                # on every rank (after one untimed frame) and take the slowest
+                probe = crt.create_buffer(sc)
+                crt.render(sc, probe)
+                t = torch.tensor([crt.render(sc, probe) * 1e3], dtype=torch.float64, device="cuda")
+                probe.close()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                single_gpu_ms = float(t.item())
+                sharding = multi_gpu.choose_sharding(W, H, spp, world, single_gpu_ms)
+                predicted = {k: round(multi_gpu.predicted_frame_ms(k, single_gpu_ms, W, H, spp, world), 3)
+                             for k in ("tiles", "samples") if multi_gpu.sharding_is_feasible(k, H, spp, world)}
+        except ValueError as e:
+            raise SystemExit(f"bench.py: {e}; nothing was measured")
+        first, count = multi_gpu.split_samples(spp, world)[rank] if sharding == "samples" else (0, spp)
 
     # Frames in flight: with more than one process the collective of frame k runs while frame k+1
     # (and the start of k+2) renders, so three sets of buffers rotate; a frame's buffers are
@@ -308,35 +474,16 @@ def main():
     else:
         rays_total = rays_rank
 
+    for b in bufs:
+        b.close()
+    for scene in scenes:
+        scene.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
-        rays_per_launch = rays_rank / args.steps
-        kernel_ms = trace_ms / args.steps
-        flops = flops_per_ray(args.scene)
-        roofline = None
-        if flops:
-            counts = REFERENCE_COUNTS[args.scene]
-            achieved = rays_per_launch * flops / (kernel_ms * 1e-3) / 1e12
-            traffic = measured_traffic(args.scene) if world == 1 and args.spp == 0 else None
-            hbm_achieved = None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9
-            roofline = {
-                "bound": "valu", "kernel": "render_fused", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4), "resolve_ms": round(resolve_ms / args.steps, 4),
-                "rays_per_launch": int(rays_per_launch),
-                "flops_per_ray": round(flops, 1),
-                "flops_model": "reference-algorithm flops: 24*N_box + 84*N_prim + 60*N_accept + 100 with the counts of the "
-                               "reference's own traversal (oracle, reduced image size), not the instructions these kernels issue",
-                "reference_counts_per_ray": {"node_pops": counts[0], "box_tests": counts[1], "prim_tests": counts[2], "accepts": counts[3]},
-                "hbm": {"achieved": None if hbm_achieved is None else round(hbm_achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": None if hbm_achieved is None else round(hbm_achieved / PEAK_HBM_GBS, 5),
-                        "source": "measured: FETCH_SIZE + WRITE_SIZE of the kernel (profiles/traffic.json) / kernel_ms",
-                        "modelled_wavefront_equivalent": {
-                            "bytes_per_ray": STATE_BYTES_PER_RAY,
-                            "GB/s": round(rays_per_launch * STATE_BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9, 1),
-                            "note": "state a multi-kernel wavefront tracer would move through HBM per ray; the fused kernel keeps it in registers",
-                            "scene_bytes_per_ray_reference_walk": round(128.0 * counts[0] + 48.0 * counts[2], 1)}}}
+        roofline = roofline_block(args.scene, rays_rank / args.steps, trace_ms / args.steps, resolve_ms / args.steps,
+                                  world == 1 and args.spp == 0)
         if not distributed:
             how = "single GPU"
         elif sharding == "tiles":
@@ -344,6 +491,11 @@ def main():
                    f"14*W*H floats + assemble kernel per frame, overlapped with the next frame")
         else:
             how = (f"sample ranges per rank ({args.scaling}), one all-reduce of 14*W*H floats per frame, overlapped with the next frame")
+        config = {"workload": f"{args.scene} {W}x{H}, {total_spp} spp in total, {bounces} bounces",
+                  "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps}
+        if single_gpu_ms is not None:
+            config["sharding_choice"] = {"single_gpu_frame_ms_measured": round(single_gpu_ms, 3), "predicted_frame_ms": predicted,
+                                         "chosen": sharding}
         out = {
             "metric": "Mrays/s (whole node) Cornell box 1000x1000, 50spp, 15 bounces" if args.scene == HEADLINE and args.spp == 0
                       else f"Mrays/s (whole node) {args.scene}",
@@ -351,10 +503,17 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak" if (distributed and args.scaling == "weak") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H}, {total_spp} spp in total, {bounces} bounces",
-                       "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps},
+            "config": config,
             "roofline": roofline,
         }
+        if world == 1 and not distributed and args.scene == HEADLINE and args.spp == 0 and not args.no_configs:
+            # the other BASELINE configurations, a few frames each, after the timed headline region
+            out["configs"] = []
+            for name, steps, warmup in OTHER_CONFIGS:
+                try:
+                    out["configs"].append(measure_config(crt, torch, name, steps, warmup))
+                except Exception as e:          # a configuration that cannot run is reported, not hidden
+                    out["configs"].append({"workload": name, "error": str(e)})
         if world == 1 and args.cpu_spp > 0:
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(scene_file, W, H, args.cpu_spp, threads)
@@ -363,9 +522,6 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
 
-    for b in bufs:
-        b.close()
-    sc.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -71,14 +71,48 @@ def predicted_frame_ms(sharding, single_gpu_ms, width, height, spp, world):
     return single_gpu_ms * share + comm
 
 
+def band_count(height, band_rows=BAND_ROWS):
+    """Number of bands an image of `height` rows is cut into."""
+    return (height + band_rows - 1) // band_rows
+
+
+def sharding_is_feasible(sharding, height, spp, world):
+    """True when EVERY rank gets work under this split: at least one sample number each for
+    'samples', at least one band of rows each for 'tiles'.  A pure function of the frame and the
+    world size, so that every rank comes to the same answer without talking to the others."""
+    if sharding == "samples":
+        return spp >= world
+    if sharding == "tiles":
+        return band_count(height) >= world
+    raise ValueError(sharding)
+
+
+def check_sharding(sharding, height, spp, world):
+    """Raises ValueError (the same one on every rank, before any collective) when `sharding` would
+    leave a rank without work: a rank that stopped on its own would leave the others waiting in
+    the collective until its timeout."""
+    if not sharding_is_feasible(sharding, height, spp, world):
+        if sharding == "samples":
+            raise ValueError(f"{spp} samples per pixel cannot be divided over {world} GPUs (a rank would get none); "
+                             f"use the tile split or fewer GPUs")
+        raise ValueError(f"an image of {height} rows has {band_count(height)} bands of {BAND_ROWS} rows, fewer than "
+                         f"{world} GPUs (a rank would own no rows); use the sample split or fewer GPUs")
+
+
 def choose_sharding(width, height, spp, world, single_gpu_ms=10.0):
-    """'tiles' or 'samples' for this frame: the cheaper prediction, samples when a rank would get
-    no rows (image lower than world * BAND_ROWS) and tiles when it would get no samples."""
+    """'tiles' or 'samples' for this frame: the cheaper prediction among the splits that give every
+    rank work (`single_gpu_ms`: the frame's render time on one GPU, measured by the caller where it
+    can be).  Raises ValueError when neither split does (fewer samples AND fewer bands than GPUs)."""
     if world == 1:
         return "samples"
-    if height < world * BAND_ROWS:
+    tiles_ok = sharding_is_feasible("tiles", height, spp, world)
+    samples_ok = sharding_is_feasible("samples", height, spp, world)
+    if not tiles_ok and not samples_ok:
+        raise ValueError(f"neither split gives each of {world} GPUs work: {spp} samples per pixel and "
+                         f"{band_count(height)} bands of {BAND_ROWS} rows; use fewer GPUs")
+    if not tiles_ok:
         return "samples"
-    if spp < world:
+    if not samples_ok:
         return "tiles"
     t = predicted_frame_ms("tiles", single_gpu_ms, width, height, spp, world)
     s = predicted_frame_ms("samples", single_gpu_ms, width, height, spp, world)

@@ -148,9 +148,42 @@ def test_sharding_choice():
     # rows of the ranks partition the image
     rows = sorted(j for r in range(3) for j in multi_gpu.band_rows_of_rank(37, r, 3))
     assert rows == list(range(37))
+    # a slow frame makes the samples split's imbalance dearer, not cheaper: still tiles
+    assert multi_gpu.choose_sharding(3840, 2160, 50, 8, single_gpu_ms=360.0) == "tiles"
+    # 1024 samples divide evenly over 8 GPUs, 9 bands do not (2 against 1.125): samples, once the frame
+    # is slow enough to outweigh the all-reduce's extra bytes
+    assert multi_gpu.choose_sharding(1000, 72, 1024, 8, single_gpu_ms=100.0) == "samples"
+    assert multi_gpu.choose_sharding(1000, 72, 1024, 8, single_gpu_ms=0.01) == "tiles"
     t8 = multi_gpu.predicted_frame_ms("tiles", 11.5, 1000, 1000, 50, 8)
     s8 = multi_gpu.predicted_frame_ms("samples", 11.5, 1000, 1000, 50, 8)
     assert t8 < s8 < 11.5
+
+
+def test_sharding_that_leaves_a_rank_without_work_is_refused_alike_on_every_rank():
+    """Feasibility is a pure function of (frame, world): every rank raises the same error before any
+    collective, none is left waiting for a rank that stopped on its own."""
+    from cudaraytracer_amd import multi_gpu
+    # 4 samples over 8 GPUs: ranks 4..7 would get none
+    assert not multi_gpu.sharding_is_feasible("samples", 1000, 4, 8)
+    with pytest.raises(ValueError, match="samples"):
+        multi_gpu.check_sharding("samples", 1000, 4, 8)
+    # 32 rows = 4 bands over 8 GPUs: ranks 4..7 would own no rows
+    assert not multi_gpu.sharding_is_feasible("tiles", 32, 64, 8)
+    with pytest.raises(ValueError, match="bands"):
+        multi_gpu.check_sharding("tiles", 32, 64, 8)
+    # 57 rows = 8 bands (the last one ragged): every rank owns rows
+    assert multi_gpu.sharding_is_feasible("tiles", 57, 1, 8)
+    assert all(multi_gpu.band_rows_of_rank(57, r, 8) for r in range(8))
+    multi_gpu.check_sharding("tiles", 57, 1, 8)
+    assert multi_gpu.choose_sharding(64, 57, 4, 8) == "tiles"
+    # neither split works: automatic choice refuses too (it used to answer "samples")
+    with pytest.raises(ValueError, match="neither"):
+        multi_gpu.choose_sharding(64, 32, 4, 8)
+    # the feasibility answer agrees with what the splits hand out
+    for spp, height, world in ((4, 32, 8), (50, 1000, 8), (8, 64, 8), (3, 24, 2)):
+        assert multi_gpu.sharding_is_feasible("samples", height, spp, world) == all(n > 0 for _, n in multi_gpu.split_samples(spp, world))
+        assert multi_gpu.sharding_is_feasible("tiles", height, spp, world) == all(
+            multi_gpu.band_rows_of_rank(height, r, world) for r in range(world))
 
 
 def test_split_helpers():
