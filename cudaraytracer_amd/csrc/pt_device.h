@@ -45,7 +45,7 @@ namespace crt {
 __device__ __forceinline__ unsigned long long lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 #ifdef CRT_PROFILE
-__device__ unsigned long long g_prof[64];
+__device__ unsigned long long g_prof[128];
 #endif
 #if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
 __device__ __forceinline__ void prof_tick(int site) {
@@ -715,6 +715,11 @@ struct FlatView {                      // part of the kernel arguments
     int32_t cuboid_end[kMaxFlatGroups + 1];  // cuboid records: [0,c0) world, [c0,c1) group 1, [c1,c2) group 2
     int32_t cuboid_quad0;
     int32_t groups;
+    // Phases of the primitive loop (traverse_flat()): candidate bits (low word) that are sphere slots, and per
+    // rotated group the bit of face zB of its last cuboid when that cuboid's far faces may wait for the near
+    // ones (-1: not in use, see flat_cuboid_shared()).
+    uint32_t sphere_bits;
+    int32_t far_shift[kMaxFlatGroups + 1];
 };
 
 struct FlatLds {
@@ -797,10 +802,20 @@ __device__ __forceinline__ void flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, floa
 // one iff the box is hit and q <= HI (distances to ordered planes are ordered, rounding is monotone):
 // one inner plane per face instead of a slab test per face.  `pos` = lanes whose reciprocal is
 // positive on the axis (face A is then the near one).
-// Record, 4 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA,xB,yA,yB inner planes} {zA,zB,-,-}.
+// Record, 4 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA,xB,yA,yB inner planes} {zA,zB,margin,-}.
+//
+// Returns a ray parameter below which no triangle of a FAR face (the face of an axis whose planes the ray
+// meets last) can be hit: the far face's triangles lie in its slab, the ray enters that slab at the far inner
+// plane (parameter qf), and hit_tri's computed t differs from the exact one by a rounding error that, measured
+// along the axis, is bounded by a small multiple of 2^-24 x (size of the scene) / sin(angle between the
+// triangle's edges).  `margin` (found by the host from exactly that bound, times 1024) moves the plane towards
+// the ray's origin: safe = min over the axes of qf - margin * |1/d|.  A candidate whose t cannot be below
+// `safe` cannot replace a closest hit that is, so traverse_flat() tests the far faces last and only where the
+// closest hit so far is not already in front of them.  -inf (nothing is skipped) for a ray with a direction
+// component so small that its reciprocal is not the true one (aabb.cuh:140), and for margin = +inf.
 template <bool WIDE>
-__device__ __forceinline__ void flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned long long pos_x, unsigned long long pos_y,
-                                                   unsigned long long pos_z, unsigned& lo_word, unsigned& hi_word) {
+__device__ __forceinline__ float flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned long long pos_x, unsigned long long pos_y,
+                                                    unsigned long long pos_z, unsigned& lo_word, unsigned& hi_word) {
     const NativeQuad c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3];
     const int present = __float_as_int(c1.z);
     const float ax = (c0.x - o.x) * inv.x, bx = (c0.y - o.x) * inv.x;
@@ -826,23 +841,30 @@ __device__ __forceinline__ void flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 in
             const unsigned long long carry = shift_in(lo_word, near_hit ^ swap);
             if constexpr (WIDE) (void)shift_in(hi_word, carry);
         }
+        return qf;
     };
+    float qx, qy, qz;
     if (present == 63) {                                                 // the usual case without the six tests
-        axis(c2.x, c2.y, o.x, inv.x, pos_x, 3);
-        axis(c2.z, c2.w, o.y, inv.y, pos_y, 3);
-        axis(c3.x, c3.y, o.z, inv.z, pos_z, 3);
+        qx = axis(c2.x, c2.y, o.x, inv.x, pos_x, 3);
+        qy = axis(c2.z, c2.w, o.y, inv.y, pos_y, 3);
+        qz = axis(c3.x, c3.y, o.z, inv.z, pos_z, 3);
     } else {
-        axis(c2.x, c2.y, o.x, inv.x, pos_x, present);
-        axis(c2.z, c2.w, o.y, inv.y, pos_y, present >> 2);
-        axis(c3.x, c3.y, o.z, inv.z, pos_z, present >> 4);
+        qx = axis(c2.x, c2.y, o.x, inv.x, pos_x, present);
+        qy = axis(c2.z, c2.w, o.y, inv.y, pos_y, present >> 2);
+        qz = axis(c3.x, c3.y, o.z, inv.z, pos_z, present >> 4);
     }
+    const float margin = c3.z;
+    const float safe = fminf(fminf(__builtin_fmaf(-margin, fabsf(inv.x), qx), __builtin_fmaf(-margin, fabsf(inv.y), qy)), __builtin_fmaf(-margin, fabsf(inv.z), qz));
+    const float steepest = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+    return steepest >= 1e8f ? -INFINITY : safe;
 }
 // Box tests of one group: its cuboids, then its other slots.  SHARED: the group's cuboids are of the
 // four-planes-per-axis kind (rotated groups), 4 quads each; else 5 quads each.
 template <bool WIDE, bool SHARED>
-__device__ __forceinline__ void flat_group_boxes(const FlatView& F, int g, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
+__device__ __forceinline__ float flat_group_boxes(const FlatView& F, int g, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
     ConstQuadPtr boxes = (ConstQuadPtr)F.boxes;
     const int first = g ? F.cuboid_end[g - 1] : 0, last = F.cuboid_end[g];
+    float safe = -INFINITY;                                              // of the group's last cuboid (flat_cuboid_shared())
     if constexpr (SHARED) {
         if (first < last) {
             ConstQuadPtr cuboids = boxes + F.cuboid_quad0 + 5 * F.cuboid_end[0];
@@ -850,13 +872,20 @@ __device__ __forceinline__ void flat_group_boxes(const FlatView& F, int g, V3 o,
             asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_x) : "v"(inv.x));
             asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_y) : "v"(inv.y));
             asm("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(pos_z) : "v"(inv.z));
-            for (int c = first; c < last; c++) flat_cuboid_shared<WIDE>(cuboids + 4 * (c - F.cuboid_end[0]), o, inv, tmin, pos_x, pos_y, pos_z, lo_word, hi_word);
+            for (int c = first; c < last; c++) safe = flat_cuboid_shared<WIDE>(cuboids + 4 * (c - F.cuboid_end[0]), o, inv, tmin, pos_x, pos_y, pos_z, lo_word, hi_word);
         }
     } else {
         ConstQuadPtr cuboids = boxes + F.cuboid_quad0;
         for (int c = first; c < last; c++) flat_cuboid<WIDE>(cuboids + 5 * c, o, inv, tmin, lo_word, hi_word);
     }
     flat_box_range<WIDE>(boxes, g ? F.box_end[g - 1] : 0, F.box_end[g], o, inv, tmin, lo_word, hi_word);
+    return safe;
+}
+// The six face bits xA xB yA yB zA zB (xA the highest) of a rotated group's cuboid that are FAR faces for a ray
+// with reciprocal direction `inv`: face B of an axis the ray runs up, face A of one it runs down.
+__device__ __forceinline__ unsigned far_faces(V3 inv) {
+    const unsigned nx = __float_as_uint(inv.x) >> 31, ny = __float_as_uint(inv.y) >> 31, nz = __float_as_uint(inv.z) >> 31;
+    return 21u + (nx << 4) + (ny << 2) + nz;
 }
 
 struct TriEval {
@@ -881,24 +910,32 @@ __device__ __forceinline__ TriEval tri_eval(V3 o, V3 d, V3 point, V3 e1, V3 e2, 
     return r;
 }
 
+// Which kinds of slot a round of the primitive loop may meet (a compile-time tag: the code of the other kind is left out)
+template <int K> struct SlotKind { static constexpr int value = K; };
+enum { kSlotAny = 0, kSlotSphere = 1, kSlotTri = 2 };
+
 template <int GROUPS, int FAST, int FEAT = kFeatAll>
 __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F, const Ray& r, float tmin, float tmax, SectionClock& clk) {
     ConstFloatPtr gx = (ConstFloatPtr)F.group_xf;
     unsigned cand_lo = 0, cand_hi = 0;
     const bool wide = (FEAT & kFeatWide) && F.slot_count > 32;   // uniform over the launch
     const V3 inv0 = slab_reciprocal(r.d, FAST);
-    if (wide) flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
-    else flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    if (wide) (void)flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    else (void)flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
     // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
     V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
+    // far faces of the groups' cuboids: their candidate bits, and the ray parameter in front of which none of them can be hit
+    unsigned far = 0;
+    float safe1 = -INFINITY, safe2 = -INFINITY;
     if constexpr (GROUPS >= 1) {
         float X[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) X[k] = gx[k];
         to_object_space(X, r.o, r.d, o1, d1);
         const V3 inv1 = slab_reciprocal(d1, FAST);
-        if (wide) flat_group_boxes<true, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
-        else flat_group_boxes<false, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
+        if (wide) safe1 = flat_group_boxes<true, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
+        else safe1 = flat_group_boxes<false, true>(F, 1, o1, inv1, tmin, cand_lo, cand_hi);
+        if (F.far_shift[1] >= 0) far = far_faces(inv1);
     }
     if constexpr (GROUPS >= 2) {
         float X[15];
@@ -906,8 +943,14 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         for (int k = 0; k < 15; k++) X[k] = gx[kXformFloats + k];
         to_object_space(X, r.o, r.d, o2, d2);
         const V3 inv2 = slab_reciprocal(d2, FAST);
-        if (wide) flat_group_boxes<true, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
-        else flat_group_boxes<false, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
+        if (wide) safe2 = flat_group_boxes<true, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
+        else safe2 = flat_group_boxes<false, true>(F, 2, o2, inv2, tmin, cand_lo, cand_hi);
+        // (group 2's boxes were tested after group 1's: its bits lie below, and group 1's have moved up by as many)
+        if (F.far_shift[1] >= 0) far <<= (F.far_shift[1] - (F.far_shift[2] >= 0 ? F.far_shift[2] : 0));
+        if (F.far_shift[2] >= 0) far |= far_faces(inv2);
+        if (F.far_shift[2] > 0) far <<= F.far_shift[2];
+    } else if constexpr (GROUPS == 1) {
+        if (F.far_shift[1] > 0) far <<= F.far_shift[1];
     }
 
     Hit best;
@@ -915,35 +958,34 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     bool best_tri = false;
     float no_lo = -INFINITY;                                   // (no box entry distances in this mode: consider())
     CRT_CLOCK(clk, kSecPrim, cand_lo);
-    while (cand_lo | cand_hi) {
+    // One candidate slot (bit `s` of the candidate words = position s of the LDS copy, stored last slot first).
+    auto test_slot = [&](int s, auto kind) {
+        constexpr int KIND = decltype(kind)::value;
         CRT_PROF(kProfPrim);
-        int bit;                                               // any order will do, see consider()
-        if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
-        else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
-        const int s = bit;                                     // the LDS copy is stored last slot first
         const float4* rec = L.slots + s * kSlotQuads;
         // record: {meta, transform, A.point.xy} {A.point.z, A.edge1} {A.edge2, B.point.x} {B.point.yz, B.edge1.xy} {B.edge1.z, B.edge2}
-        // (sphere: {meta, transform, centre.xy} {centre.z, radius, centre direction.xy} {centre direction.z, -, -, -}).
+        // (sphere: {meta, transform, centre.xy} {centre.z, radius, centre direction.xy} {centre direction.z, -, -, -}
+        //          {anchor, translation.x} {translation.yz, -, -}).
         // Triangle B's part is only loaded after triangle A has been dealt with: eight registers fewer at the loop's peak.
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const int meta = __float_as_int(q0.x), xf = __float_as_int(q0.y);
         const int rank_a = meta & 63, rank_b = (meta >> 6) & 63, group = (meta >> 15) & 3;
         const bool has_b = (meta >> 12) & 1, is_tri = ((meta >> 13) & 3) == 2;
-        // the ray of the slot's group, component by component (selects in registers: written with
-        // branches, the compiler may turn the three rays into an indexed array in scratch memory)
-        V3 o = r.o, d = r.d;
-        if constexpr (GROUPS >= 1) {
-            const bool g1 = group == 1;
-            o.x = g1 ? o1.x : o.x; o.y = g1 ? o1.y : o.y; o.z = g1 ? o1.z : o.z;
-            d.x = g1 ? d1.x : d.x; d.y = g1 ? d1.y : d.y; d.z = g1 ? d1.z : d.z;
-        }
-        if constexpr (GROUPS >= 2) {
-            const bool g2 = group == 2;
-            o.x = g2 ? o2.x : o.x; o.y = g2 ? o2.y : o.y; o.z = g2 ? o2.z : o.z;
-            d.x = g2 ? d2.x : d.x; d.y = g2 ? d2.y : d.y; d.z = g2 ? d2.z : d.z;
-        }
-        if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
-        if (!(FEAT & kFeatSphere) || is_tri) {
+        if (KIND == kSlotTri || (KIND == kSlotAny && (!(FEAT & kFeatSphere) || is_tri))) {
+            // the ray of the slot's group, component by component (selects in registers: written with
+            // branches, the compiler may turn the three rays into an indexed array in scratch memory)
+            V3 o = r.o, d = r.d;
+            if constexpr (GROUPS >= 1) {
+                const bool g1 = group == 1;
+                o.x = g1 ? o1.x : o.x; o.y = g1 ? o1.y : o.y; o.z = g1 ? o1.z : o.z;
+                d.x = g1 ? d1.x : d.x; d.y = g1 ? d1.y : d.y; d.z = g1 ? d1.z : d.z;
+            }
+            if constexpr (GROUPS >= 2) {
+                const bool g2 = group == 2;
+                o.x = g2 ? o2.x : o.x; o.y = g2 ? o2.y : o.y; o.z = g2 ? o2.z : o.z;
+                d.x = g2 ? d2.x : d.x; d.y = g2 ? d2.y : d.y; d.z = g2 ? d2.z : d.z;
+            }
+            if ((FEAT & kFeatSlotXf) && xf >= 0) { CRT_PROF(kProfXform); to_object_space(xform_record<FEAT>(L.xforms, xf), (FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation), r.o, r.d, o, d); }
             const TriEval A = tri_eval(o, d, v3(q0.z, q0.w, q1.x), v3(q1.y, q1.z, q1.w), v3(q2.x, q2.y, q2.z), tmin, tmax, FAST);
             consider<!(FEAT & kFeatSphere)>(best, best_tri, no_lo, A.ok, A.t, -INFINITY, rank_a, true, A.u, A.v);
             float bx = q2.w;
@@ -951,9 +993,22 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             const float4 q3 = rec[3], q4 = rec[4];
             const TriEval B = tri_eval(o, d, v3(bx, q3.x, q3.y), v3(q3.z, q3.w, q4.x), v3(q4.y, q4.z, q4.w), tmin, tmax, FAST);
             consider<!(FEAT & kFeatSphere)>(best, best_tri, no_lo, B.ok && has_b, B.t, -INFINITY, rank_b, true, B.u, B.v);
-        } else {
-            // sphere slot: {c0.xyz, radius} {cd.xyz, 0}.  The root the reference would take does not
-            // depend on the upper bound: the near root if it is beyond tmin, else the far one.
+        } else if constexpr ((FEAT & kFeatSphere) != 0 && KIND != kSlotTri) {
+            // Sphere slot (always in the world group).  Its transform is nearly always the rotation-free one the reference
+            // gives every sphere (anchor = centre): anchor and translation then come with the slot record.
+            V3 o = r.o, d = r.d;
+            if ((FEAT & kFeatSlotXf) && xf >= 0) {
+                if ((FEAT & kFeatPlainXf) && (xf & kXfIdentityRotation)) {
+                    const float4 q3 = rec[3], q4 = rec[4];
+                    const V3 anchor = v3(q3.x, q3.y, q3.z), trans = v3(q3.w, q4.x, q4.y);
+                    o = (r.o - anchor - trans) + anchor;           // hittable.cuh:429 with the identity matrix
+                } else {
+                    CRT_PROF(kProfXform);
+                    to_object_space(xform_record<FEAT>(L.xforms, xf), false, r.o, r.d, o, d);
+                }
+            }
+            // The root the reference would take does not depend on the upper bound: the near root if it is
+            // beyond tmin, else the far one.
             V3 center = v3(q0.z, q0.w, q1.x) + v3(q1.z, q1.w, q2.x) * r.time;
             V3 oc = o - center;
             float a = length_squared(d);
@@ -966,6 +1021,53 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             float root = (tmin < r1 && r1 < tmax) ? r1 : r2;
             bool ok = !(disc < 0.0f) && (tmin < root && root < tmax);
             consider(best, best_tri, no_lo, ok, root, -INFINITY, rank_a, false, 0.0f, 0.0f);
+        }
+    };
+    // Any order of the tests gives the same hit (consider()), so the candidates are taken in three phases, each a
+    // loop of its own in which every lane runs the same code: sphere slots; triangle slots; the far faces of the
+    // rotated groups' cuboids, and those only for rays whose closest hit so far is not already in front of them
+    // (flat_cuboid_shared(): a ray that crosses a box meets two of its faces, the far one to no purpose).
+    far &= cand_lo;
+    cand_lo ^= far;
+#if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
+    {   // candidates per lane (slots 16-23), their maximum over the wave (24-31), and which slots the lanes with three or more hold (64-127)
+        const int n = __builtin_popcount(cand_lo) + __builtin_popcount(cand_hi) + __builtin_popcount(far);
+        atomicAdd(&g_prof[16 + (n < 7 ? n : 7)], 1ull);
+        int most = n;
+        for (int off = 32; off; off >>= 1) most = max(most, __shfl_xor(most, off));
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(lanes_where(true))) atomicAdd(&g_prof[24 + (most < 7 ? most : 7)], 1ull);
+        if (n >= 3)
+            for (unsigned m = cand_lo | far; m; m &= m - 1u) atomicAdd(&g_prof[64 + __builtin_ctz(m)], 1ull);
+    }
+#endif
+    if constexpr ((FEAT & kFeatSphere) != 0) {
+        unsigned spheres = cand_lo & F.sphere_bits;
+        cand_lo ^= spheres;
+        while (spheres) {
+            const int bit = __builtin_ctz(spheres);
+            spheres &= spheres - 1u;
+            test_slot(bit, SlotKind<kSlotSphere>());
+        }
+    }
+    // A lane turns to its far faces when its own near candidates are used up.
+    const unsigned faces1 = F.far_shift[1] >= 0 ? 63u << F.far_shift[1] : 0u, faces2 = F.far_shift[2] >= 0 ? 63u << F.far_shift[2] : 0u;
+    while (true) {
+        if constexpr (GROUPS >= 1) {
+            if (cand_lo == 0u && far != 0u) {
+                if (best.t < safe1) far &= ~faces1;
+                if (GROUPS >= 2 && best.t < safe2) far &= ~faces2;
+                cand_lo = far;
+                far = 0u;
+            }
+        }
+        if (!lanes_where((cand_lo | cand_hi) != 0u)) break;
+        if (cand_lo | cand_hi) {
+            int bit;
+            if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
+            else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
+            // (beyond 32 slots the high word may hold spheres)
+            if constexpr ((FEAT & kFeatWide) != 0) test_slot(bit, SlotKind<kSlotAny>());
+            else test_slot(bit, SlotKind<kSlotTri>());
         }
     }
     return best;

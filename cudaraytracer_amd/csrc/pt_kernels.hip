@@ -1295,7 +1295,7 @@ void launch_flat_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds)
 int variant_features(const crt_scene* sc) {
     if (kernel_mode(sc) == kModeFlat) {
         if ((sc->features & ~kFeatBasicXform) == 0) return kFeatBasicXform;
-        return (sc->features & kFeatPlainXf) ? kFeatAll : (kFeatAll & ~kFeatPlainXf);
+        return (sc->features & kFeatWide) ? kFeatAll : (kFeatAll & ~kFeatWide);
     }
     // the flat mode's feature bits say nothing about a tree walk
     return (sc->features & ~(kFeatSlotXf | kFeatWide)) == 0 ? kFeatBasic : kFeatAll;
@@ -1304,7 +1304,7 @@ template <int GROUPS>
 void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
     switch (variant_features(sc)) {
     case kFeatBasicXform: launch_flat_feat<GROUPS, kFeatBasicXform>(sc, A, grid, lds); break;
-    case kFeatAll & ~kFeatPlainXf: launch_flat_feat<GROUPS, kFeatAll & ~kFeatPlainXf>(sc, A, grid, lds); break;
+    case kFeatAll & ~kFeatWide: launch_flat_feat<GROUPS, kFeatAll & ~kFeatWide>(sc, A, grid, lds); break;
     default: launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds); break;
     }
 }
@@ -1388,6 +1388,37 @@ bool fast_reciprocal_is_exact(const crt_scene_desc* d) {
     // are not proven but practically certain: a scattered direction is normal + unit vector with a component
     // beyond 1e-8, a reflection plus a bounded fuzz vector, a refraction, or a camera ray.)
     return std::isfinite(dir_object) && std::isfinite(edges) && dir_object < 0x1p48 && edges * dir_object < 0x1p99;
+}
+
+// The largest distance between a point a ray can start from (the camera's ray origins, any surface) and a point
+// of the scene: the diagonal of the box around every object's box and the camera.
+double scene_reach(const crt_scene_desc* d) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto add = [&](double x, double y, double z) {
+        const double p[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) { lo[a] = std::fmin(lo[a], p[a]); hi[a] = std::fmax(hi[a], p[a]); }
+    };
+    for (int i = 0; i < d->object_count; i++) {
+        const crt_object& o = d->objects[i];
+        if (!o.visible) continue;
+        add(o.bbox_min[0], o.bbox_min[1], o.bbox_min[2]);
+        add(o.bbox_max[0], o.bbox_max[1], o.bbox_max[2]);
+    }
+    const crt_camera& c = d->camera;
+    const double w = d->render.image_width + 1.0, h = d->render.image_height + 1.0;
+    for (int corner = 0; corner < 4; corner++) {
+        const double i = (corner & 1) ? w : -1.0, j = (corner & 2) ? h : -1.0;
+        double p[3];
+        for (int a = 0; a < 3; a++) p[a] = c.lower_left_corner[a] + i * c.pixel_delta_u[a] + j * c.pixel_delta_v[a];
+        if (c.type != CRT_CAM_PERSPECTIVE) add(p[0], p[1], p[2]);              // orthographic rays start on the view plane
+    }
+    for (int su = -1; su <= 1; su += 2)
+        for (int sv = -1; sv <= 1; sv += 2)
+            add(c.center[0] + su * c.defocus_disk_u[0] + sv * c.defocus_disk_v[0], c.center[1] + su * c.defocus_disk_u[1] + sv * c.defocus_disk_v[1],
+                c.center[2] + su * c.defocus_disk_u[2] + sv * c.defocus_disk_v[2]);
+    double sq = 0.0;
+    for (int a = 0; a < 3; a++) sq += (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    return std::sqrt(sq);
 }
 
 // Leaf slots in the order the reference's traversal visits them when every box is hit
@@ -1617,7 +1648,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     if (opt.accel < CRT_ACCEL_AUTO || opt.accel > CRT_ACCEL_ORDERED) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->accel must be CRT_ACCEL_*");
     if (opt.mode < 0 || opt.mode > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->mode must be 0..3");
     if (opt.general_kernel < 0 || opt.general_kernel > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->general_kernel must be 0 or 1");
-    if (opt.flat_cuboids < 0 || opt.flat_cuboids > 2) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..2");
+    if (opt.flat_cuboids < 0 || opt.flat_cuboids > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..3");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
         return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
@@ -1804,7 +1835,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     std::vector<float> flat_box_rec, flat_slot_rec, flat_group_xf;
     std::vector<int32_t> flat_ent_obj;
     int flat_groups = 0, flat_box_end[kMaxFlatGroups + 1] = {0, 0, 0}, flat_cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
-    int flat_cuboid_quad0 = 0, flat_slot_count = 0;
+    int flat_cuboid_quad0 = 0, flat_slot_count = 0, flat_far_shift[kMaxFlatGroups + 1] = {-1, -1, -1};
+    uint32_t flat_sphere_bits = 0;
     bool flat_slot_xf = false;       // some flat slot's primitives carry their own transform
     bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
     if (can_flat) {
@@ -1968,6 +2000,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             std::vector<Slot> ordered_slots;
             std::vector<float> cuboid_rec;
             int box_end[kMaxFlatGroups + 1] = {0, 0, 0}, cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
+            int far_cuboid_last_slot[kMaxFlatGroups + 1] = {-1, -1, -1};
             for (int g = 0; g <= kMaxFlatGroups; g++) {
                 for (const Cuboid& cu : cuboids) {
                     if (cu.group != g) continue;
@@ -1988,12 +2021,37 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                         }
                         cuboid_rec.insert(cuboid_rec.end(), rec, rec + 20);
                     } else {                                                      // flat_cuboid_shared(): four planes per axis
+                        float thinnest = INFINITY;
                         for (int x = 0; x < 3; x++) {
                             const float lo = cu.outer[2 * x], hi = cu.outer[2 * x + 1];
                             const float pad = 0.001f + 2e-5f * std::fmax(std::fabs(lo), std::fabs(hi));
                             rec[2 * x] = lo - pad; rec[2 * x + 1] = hi + pad;
                             rec[8 + 2 * x] = lo + pad; rec[8 + 2 * x + 1] = hi - pad;
+                            thinnest = std::fmin(thinnest, hi - lo);
                         }
+                        // Far faces wait for the near ones (flat_cuboid_shared()) in a group's last cuboid when it has all
+                        // six faces.  The margin: hit_tri's t, measured along a face's axis, is off by at most about
+                        // 20 x 2^-24 x reach / sin(angle between the triangle's edges), reach = the largest distance
+                        // between a ray origin and a point of the scene; 1024 times that bound, and no more than an
+                        // eighth of the cuboid's thinnest side (else the faces are simply all tested).
+                        float margin = INFINITY;
+                        far_cuboid_last_slot[g] = -1;                             // (the group's LAST cuboid is the one: its distance is what the box phase hands on)
+                        if (present == 63) {
+                            double sine = 1.0;
+                            for (int k = 0; k < 6; k++) {
+                                const Slot& sl = slots[(size_t)cu.face_slot[k]];
+                                for (int which = 0; which < (sl.has_b ? 2 : 1); which++) {
+                                    const crt_object& t = d->objects[flat_ent_obj[which ? sl.rank_b : sl.rank_a]];
+                                    const V3 e1 = v3(t.p1), e2 = v3(t.p2);
+                                    const double area = length(cross(e1, e2)), sides = (double)length(e1) * length(e2);
+                                    sine = std::fmin(sine, sides > 0.0 ? area / sides : 0.0);
+                                }
+                            }
+                            const double m = 0x1p-14 * scene_reach(d) / sine;
+                            if (sine > 0.0 && std::isfinite(m) && m <= 0.125 * thinnest) margin = (float)m;
+                        }
+                        rec[14] = margin;
+                        if (std::isfinite(margin)) far_cuboid_last_slot[g] = (int)ordered_slots.size() - 1;   // its face zB
                         cuboid_rec.insert(cuboid_rec.end(), rec, rec + 16);
                     }
                     cuboid_end[g]++;
@@ -2012,6 +2070,13 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             flat_cuboid_quad0 = (int)(flat_box_rec.size() / 4);
             flat_box_rec.insert(flat_box_rec.end(), cuboid_rec.begin(), cuboid_rec.end());
             flat_slot_count = (int)ordered_slots.size();
+            // candidate bit of slot s = slot_count - 1 - s (the first slot tested ends up highest)
+            for (int g = 1; g <= kMaxFlatGroups; g++) {
+                const int bit = far_cuboid_last_slot[g] < 0 ? -1 : flat_slot_count - 1 - far_cuboid_last_slot[g];
+                flat_far_shift[g] = (bit >= 0 && bit + 6 <= 32 && opt.flat_cuboids != 3) ? bit : -1;
+            }
+            for (int s = 0; s < flat_slot_count; s++)
+                if (ordered_slots[(size_t)s].type != CRT_OBJ_TRI && flat_slot_count - 1 - s < 32) flat_sphere_bits |= 1u << (flat_slot_count - 1 - s);
             for (const Slot& sl : ordered_slots) {
                 float rec[kSlotQuads * 4] = {0};
                 const crt_object& A = d->objects[flat_ent_obj[sl.rank_a]];
@@ -2023,6 +2088,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                 } else {
                     rec[2] = A.p0[0]; rec[3] = A.p0[1]; rec[4] = A.p0[2]; rec[5] = A.p2[0];
                     rec[6] = A.p1[0]; rec[7] = A.p1[1]; rec[8] = A.p1[2];
+                    // anchor and translation of the sphere's own transform (read when it has no rotation)
+                    for (int k = 0; k < 3; k++) { rec[12 + k] = A.anchor[k]; rec[15 + k] = A.translation[k]; }
                 }
                 const int32_t meta = sl.rank_a | (sl.rank_b << 6) | ((sl.has_b ? 1 : 0) << 12) | (sl.type << 13) | (sl.group << 15);
                 rec[0] = as_float(meta);
@@ -2156,6 +2223,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     for (int g = 0; g <= kMaxFlatGroups; g++) { sc->flat.box_end[g] = flat_box_end[g]; sc->flat.cuboid_end[g] = flat_cuboid_end[g]; }
     sc->flat.cuboid_quad0 = flat_cuboid_quad0;
     sc->flat.groups = flat_groups;
+    sc->flat.sphere_bits = flat_sphere_bits;
+    for (int g = 0; g <= kMaxFlatGroups; g++) sc->flat.far_shift[g] = flat_far_shift[g];
     sc->lds_flat_bytes = (int)((size_t)sc->flat.slot_count * kSlotQuads * 16 + xforms.size() * 4);
     sc->mode = opt.mode;
     sc->opt = opt;
@@ -2457,11 +2526,11 @@ int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms) {
 int crt_profile_counters(uint64_t* out64, int reset) {
     crt::clear_error();
 #ifdef CRT_PROFILE
-    unsigned long long host[64];
+    unsigned long long host[128];
     if (out64) {
         CRT_HIP(hipDeviceSynchronize());
         CRT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(crt::g_prof), sizeof(host)));
-        for (int i = 0; i < 64; i++) out64[i] = host[i];
+        for (int i = 0; i < 128; i++) out64[i] = host[i];
     }
     if (reset) {
         std::memset(host, 0, sizeof(host));

@@ -202,7 +202,9 @@ typedef struct crt_scene_options {
     int32_t wavefront_paths;  /* path slots (224 bytes each) of the wavefront buffers; 0 = 67 108 864   */
     int32_t flat_cuboids;     /* small scenes: 0 or 1 = slots whose boxes share planes like the faces of an axis-aligned
                                  box (a box object, the walls of a room) are box-tested together (default; same
-                                 candidates, fewer operations), 2 = every slot on its own                */
+                                 candidates, fewer operations), 2 = every slot on its own, 3 = together, but the far
+                                 faces of a rotated box are tested with its near ones instead of after them and only
+                                 where the closest hit is not already in front of them (same hits, for comparison) */
     int32_t general_kernel;   /* 1: always run the kernel variant compiled for every scene feature (spheres, textures,
                                  metal and glass, camera kinds ...) instead of the one compiled for just what the
                                  scene contains; same results, for comparison                         */
@@ -300,10 +302,11 @@ void* crt_scene_stream(crt_scene* sc);
 int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms);
 
 /* Development aid: loop-occupancy counters of a library built with -DCRT_PROFILE
- * (64 values: site k < 16 -> [2k] wave-level executions, [2k+1] active lanes; [32+s] shader
- * clocks the waves spent in section s of the path loop).  The product build returns
- * CRT_ERR_UNSUPPORTED. */
-int crt_profile_counters(uint64_t* out64, int reset);
+ * (128 values: site k < 8 -> [2k] wave-level executions, [2k+1] active lanes; flat mode: [16+n] rays
+ * with n candidate slots (7 = seven or more), [24+n] waves whose fullest lane held n, [64+b] how
+ * often candidate bit b was set in a lane with three or more; [32+s] shader clocks the waves spent
+ * in section s of the path loop).  The product build returns CRT_ERR_UNSUPPORTED. */
+int crt_profile_counters(uint64_t* out128, int reset);
 
 /* How the kernels reach the geometry: 0 = automatic (default), 1 = BVH4 walk with the scene in
  * HBM, 2 = BVH4 walk over an LDS copy of the scene (small scenes), 3 = flat box loop with a

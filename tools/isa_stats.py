@@ -36,11 +36,18 @@ print(dict(cls), "total", sum(cls.values()))
 for k in ("v_readlane_b32", "v_writelane_b32", "v_readfirstlane_b32", "v_cndmask_b32_e32", "v_cndmask_b32_e64", "v_mov_b32_e32", "s_mov_b32", "s_mov_b64"):
     print(f"  {k}: {ops[k]}", end="")
 print()
-# metadata of the kernel
+# metadata of the kernel (the YAML keys of one kernel are sorted: group_segment... comes before .name, the others after)
 name = lines[start].split(":")[0]
 for i, l in enumerate(lines):
-    if l.strip().startswith(".name:") and name in l:
-        for j in range(i - 25, i + 25):
-            if any(t in lines[j] for t in ("sgpr_count", "vgpr_count", "spill_count", "private_segment_fixed", "group_segment_fixed")):
+    if l.strip().startswith(".name:") and l.strip().endswith(name):
+        for j in range(i - 1, max(0, i - 40), -1):
+            if lines[j].strip().startswith("- .args") or ".name:" in lines[j]:
+                break
+            if "group_segment_fixed" in lines[j]:
+                print("  ", lines[j].strip())
+        for j in range(i + 1, min(len(lines), i + 40)):
+            if lines[j].strip().startswith("- .args") or ".name:" in lines[j]:
+                break
+            if any(t in lines[j] for t in ("sgpr_count", "vgpr_count", "spill_count", "private_segment_fixed")):
                 print("  ", lines[j].strip())
         break

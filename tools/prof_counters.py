@@ -16,7 +16,7 @@ buf = crt.create_buffer(sc)
 lib = crt.lib()
 assert lib.crt_profile_counters(None, 1) == 0, lib.crt_last_error()
 secs = crt.render(sc, buf)
-out = np.zeros(64, np.uint64)
+out = np.zeros(128, np.uint64)
 lib.crt_profile_counters(out.ctypes.data, 0)
 rays = api.last_ray_count
 names = ["outer", "regen", "trace", "node", "prim", "shade", "reject", "xform"]
@@ -25,6 +25,12 @@ for k, n in enumerate(names):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
     if w:
         print(f"{n:8s} wave-execs {w:12d}  lanes {l:14d}  util {l / (64.0 * w):6.3f}  wave-execs/ray*64 {w * 64.0 / rays:7.3f}  lanes/ray {l / rays:7.3f}")
+if int(out[16:32].sum()):
+    lanes, waves = out[16:24].astype(float), out[24:32].astype(float)
+    print("flat mode, candidate slots per ray   :", " ".join(f"{k}:{v / lanes.sum() * 100:5.1f}%" for k, v in enumerate(lanes)))
+    print("flat mode, fullest lane of the wave  :", " ".join(f"{k}:{v / waves.sum() * 100:5.1f}%" for k, v in enumerate(waves)),
+          f" mean {sum(k * v for k, v in enumerate(waves)) / waves.sum():.3f}")
+    print("candidate bits of rays with >= 3     :", " ".join(f"{b}:{int(v)}" for b, v in enumerate(out[64:128]) if v))
 secs_names = ["other", "regen", "box", "prim", "surface", "sample", "scatter", "node"]
 tot = float(sum(int(out[32 + k]) for k in range(8)))
 if tot:
