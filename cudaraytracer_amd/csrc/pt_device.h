@@ -1040,7 +1040,10 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             for (unsigned m = cand_lo | far; m; m &= m - 1u) atomicAdd(&g_prof[64 + __builtin_ctz(m)], 1ull);
     }
 #endif
-    if constexpr ((FEAT & kFeatSphere) != 0) {
+#ifndef CRT_NO_SPHERE_PHASE
+#define CRT_NO_SPHERE_PHASE 0
+#endif
+    if constexpr ((FEAT & kFeatSphere) != 0 && !CRT_NO_SPHERE_PHASE) {
         unsigned spheres = cand_lo & F.sphere_bits;
         cand_lo ^= spheres;
         while (spheres) {
@@ -1051,23 +1054,25 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     }
     // A lane turns to its far faces when its own near candidates are used up.
     const unsigned faces1 = F.far_shift[1] >= 0 ? 63u << F.far_shift[1] : 0u, faces2 = F.far_shift[2] >= 0 ? 63u << F.far_shift[2] : 0u;
-    while (true) {
-        if constexpr (GROUPS >= 1) {
+    auto next_slot = [&]() {
+        int bit;
+        if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
+        else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
+        // (beyond 32 slots the high word may hold spheres)
+        if constexpr ((FEAT & kFeatWide) != 0 || (CRT_NO_SPHERE_PHASE && (FEAT & kFeatSphere) != 0)) test_slot(bit, SlotKind<kSlotAny>());
+        else test_slot(bit, SlotKind<kSlotTri>());
+    };
+    if constexpr (GROUPS == 0) {
+        while (cand_lo | cand_hi) next_slot();
+    } else {
+        while (cand_lo | cand_hi | far) {
             if (cand_lo == 0u && far != 0u) {
                 if (best.t < safe1) far &= ~faces1;
                 if (GROUPS >= 2 && best.t < safe2) far &= ~faces2;
                 cand_lo = far;
                 far = 0u;
             }
-        }
-        if (!lanes_where((cand_lo | cand_hi) != 0u)) break;
-        if (cand_lo | cand_hi) {
-            int bit;
-            if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
-            else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
-            // (beyond 32 slots the high word may hold spheres)
-            if constexpr ((FEAT & kFeatWide) != 0) test_slot(bit, SlotKind<kSlotAny>());
-            else test_slot(bit, SlotKind<kSlotTri>());
+            if (cand_lo | cand_hi) next_slot();
         }
     }
     return best;

@@ -8,6 +8,6 @@ for S in $SCENES; do
   for L in $LIBS; do
     if [ "$L" = "-" ]; then unset CRT_LIB; else export CRT_LIB=$PWD/cudaraytracer_amd/libcrt_hip_$L.so; fi
     echo "== $NAME lib=$L"
-    timeout -k 10 200 python3 tools/quick_perf.py $NAME 4 $SPP 2>&1 | grep -E "rep[1-3]|Error|error" || exit 1
+    timeout -k 10 200 python3 tools/quick_perf.py $NAME ${REPS:-13} $SPP 2>&1 | grep -E "summary|Error|error" || exit 1
   done
 done

@@ -22,9 +22,13 @@ t_up = time.time()
 sc.upload()
 print(f"{name}: upload {time.time() - t_up:.2f} s", flush=True)
 buf = crt.create_buffer(sc)
+times = []
 for r in range(reps):
     t0 = time.time()
     secs = crt.render(sc, buf)
     wall = time.time() - t0
     rays = api.last_ray_count
+    times.append(secs)
     print(f"{name} rep{r}: device {secs*1e3:.2f} ms wall {wall*1e3:.2f} ms rays {rays} -> {rays/secs/1e6:.1f} Mrays/s", flush=True)
+warm = sorted(times[1:] or times)
+print(f"{name} summary: median {warm[len(warm) // 2]*1e3:.3f} ms  min {warm[0]*1e3:.3f} ms  over {len(warm)} warm frames  ({sc.describe()})", flush=True)
