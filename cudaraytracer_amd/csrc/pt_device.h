@@ -720,6 +720,9 @@ struct FlatView {                      // part of the kernel arguments
     // ones (-1: not in use, see flat_cuboid_shared()).
     uint32_t sphere_bits;
     int32_t far_shift[kMaxFlatGroups + 1];
+    // The world group's last cuboid (its faces keep their own intervals and may be absent): candidate bit of face
+    // A and of face B per axis (0 = absent or not in use), for the same purpose.
+    uint32_t world_face_a[3], world_face_b[3];
 };
 
 struct FlatLds {
@@ -767,8 +770,10 @@ __device__ __forceinline__ void flat_box_range(ConstQuadPtr boxes, int first, in
 // exact, so each face gets the same bit as its own slab test would give it.
 // Record, 5 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA lo,hi, xB lo,hi} {yA.., yB..} {zA.., zB..};
 // bits are shifted in for the present faces only, in the order xA xB yA yB zA zB.
+// Returns the ray parameter in front of which no triangle of a far face can be hit (see flat_cuboid_shared());
+// -inf without a margin (record word [1].w: +inf).
 template <bool WIDE>
-__device__ __forceinline__ void flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
+__device__ __forceinline__ float flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned& lo_word, unsigned& hi_word) {
     const NativeQuad c0 = rec[0], c1 = rec[1];
     const int present = __float_as_int(c1.z);
     const float ax = (c0.x - o.x) * inv.x, bx = (c0.y - o.x) * inv.x;
@@ -793,6 +798,13 @@ __device__ __forceinline__ void flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, floa
     if (present & 8) face(ty.z, ty.w, o.y, inv.y, nx, nz, fx, fz);
     if (present & 16) face(tz.x, tz.y, o.z, inv.z, nx, ny, fx, fy);
     if (present & 32) face(tz.z, tz.w, o.z, inv.z, nx, ny, fx, fy);
+    // The far face of an axis is B for a ray that runs up the axis, A for one that runs down; its slab begins at
+    // the plane facing the ray's origin (B's lower, A's upper one).  The host stores -inf / +inf there for an absent
+    // face, which then bars nothing.
+    const float margin = c1.w;
+    const float px = inv.x < 0.0f ? tx.y : tx.z, py = inv.y < 0.0f ? ty.y : ty.z, pz = inv.z < 0.0f ? tz.y : tz.z;
+    const float qx = (px - o.x) * inv.x, qy = (py - o.y) * inv.y, qz = (pz - o.z) * inv.z;
+    return fminf(fminf(__builtin_fmaf(-margin, fabsf(inv.x), qx), __builtin_fmaf(-margin, fabsf(inv.y), qy)), __builtin_fmaf(-margin, fabsf(inv.z), qz));
 }
 // A cuboid of a rotated group.  The boxes of a group's slots are not the reference's (they only
 // have to contain their triangles), so here the six face boxes are laid out on FOUR planes per axis,
@@ -805,14 +817,19 @@ __device__ __forceinline__ void flat_cuboid(ConstQuadPtr rec, V3 o, V3 inv, floa
 // Record, 4 quads: {outer xlo,xhi,ylo,yhi} {outer zlo,zhi, present-face bits, -} {xA,xB,yA,yB inner planes} {zA,zB,margin,-}.
 //
 // Returns a ray parameter below which no triangle of a FAR face (the face of an axis whose planes the ray
-// meets last) can be hit: the far face's triangles lie in its slab, the ray enters that slab at the far inner
-// plane (parameter qf), and hit_tri's computed t differs from the exact one by a rounding error that, measured
-// along the axis, is bounded by a small multiple of 2^-24 x (size of the scene) / sin(angle between the
-// triangle's edges).  `margin` (found by the host from exactly that bound, times 1024) moves the plane towards
-// the ray's origin: safe = min over the axes of qf - margin * |1/d|.  A candidate whose t cannot be below
-// `safe` cannot replace a closest hit that is, so traverse_flat() tests the far faces last and only where the
-// closest hit so far is not already in front of them.  -inf (nothing is skipped) for a ray with a direction
-// component so small that its reciprocal is not the true one (aabb.cuh:140), and for margin = +inf.
+// meets last) can be accepted by hit_tri.  The far face's triangles lie in its slab, which the ray enters at the
+// slab's plane facing the origin (parameter qf).  Two cases, `margin` (from the host) covering both:
+//   * the ray is not nearly parallel to the face: the computed t differs from the exact one by a rounding error
+//     that, measured along the face's axis, is at most about 20 x 2^-24 x reach / sin(angle between the triangle's
+//     edges), reach = the largest distance between a ray origin and a point of the scene (the 1/|d_axis| of the
+//     error of t cancels against the d_axis that turns t into a distance along the axis); margin is 1024 times that;
+//   * the ray is so nearly parallel that the computed determinant is mostly rounding error (this includes the
+//     directions whose reciprocal is the substitute of aabb.cuh:140): a safe distance > 0 puts the origin more than
+//     `margin` away from the slab, and then one of the computed barycentrics is at least margin / (50 x 2^-24 x edge
+//     length) >> 1 in magnitude: the candidate is rejected whatever its t.
+// So safe = min over the axes of qf - margin * |1/d_axis|: a candidate whose t cannot be below `safe` cannot
+// replace a closest hit that is, and traverse_flat() tests the far faces last and only where the closest hit so
+// far is not already in front of them.  margin = +inf gives -inf: nothing is skipped.
 template <bool WIDE>
 __device__ __forceinline__ float flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 inv, float tmin, unsigned long long pos_x, unsigned long long pos_y,
                                                     unsigned long long pos_z, unsigned& lo_word, unsigned& hi_word) {
@@ -854,9 +871,7 @@ __device__ __forceinline__ float flat_cuboid_shared(ConstQuadPtr rec, V3 o, V3 i
         qz = axis(c3.x, c3.y, o.z, inv.z, pos_z, present >> 4);
     }
     const float margin = c3.z;
-    const float safe = fminf(fminf(__builtin_fmaf(-margin, fabsf(inv.x), qx), __builtin_fmaf(-margin, fabsf(inv.y), qy)), __builtin_fmaf(-margin, fabsf(inv.z), qz));
-    const float steepest = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
-    return steepest >= 1e8f ? -INFINITY : safe;
+    return fminf(fminf(__builtin_fmaf(-margin, fabsf(inv.x), qx), __builtin_fmaf(-margin, fabsf(inv.y), qy)), __builtin_fmaf(-margin, fabsf(inv.z), qz));
 }
 // Box tests of one group: its cuboids, then its other slots.  SHARED: the group's cuboids are of the
 // four-planes-per-axis kind (rotated groups), 4 quads each; else 5 quads each.
@@ -876,7 +891,7 @@ __device__ __forceinline__ float flat_group_boxes(const FlatView& F, int g, V3 o
         }
     } else {
         ConstQuadPtr cuboids = boxes + F.cuboid_quad0;
-        for (int c = first; c < last; c++) flat_cuboid<WIDE>(cuboids + 5 * c, o, inv, tmin, lo_word, hi_word);
+        for (int c = first; c < last; c++) safe = flat_cuboid<WIDE>(cuboids + 5 * c, o, inv, tmin, lo_word, hi_word);
     }
     flat_box_range<WIDE>(boxes, g ? F.box_end[g - 1] : 0, F.box_end[g], o, inv, tmin, lo_word, hi_word);
     return safe;
@@ -920,8 +935,14 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     unsigned cand_lo = 0, cand_hi = 0;
     const bool wide = (FEAT & kFeatWide) && F.slot_count > 32;   // uniform over the launch
     const V3 inv0 = slab_reciprocal(r.d, FAST);
-    if (wide) (void)flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
-    else (void)flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    float safe0;
+    if (wide) safe0 = flat_group_boxes<true, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    else safe0 = flat_group_boxes<false, false>(F, 0, r.o, inv0, tmin, cand_lo, cand_hi);
+    // far faces of the world group's last cuboid, at their final bit positions
+    const unsigned world_faces = F.world_face_a[0] | F.world_face_b[0] | F.world_face_a[1] | F.world_face_b[1] | F.world_face_a[2] | F.world_face_b[2];
+    unsigned far0 = 0;
+    if (world_faces) far0 = (inv0.x < 0.0f ? F.world_face_a[0] : F.world_face_b[0]) | (inv0.y < 0.0f ? F.world_face_a[1] : F.world_face_b[1]) |
+                            (inv0.z < 0.0f ? F.world_face_a[2] : F.world_face_b[2]);
     // rays of the rotated groups (hittable.cuh:429-430), transform data through scalar loads
     V3 o1 = r.o, d1 = r.d, o2 = r.o, d2 = r.d;
     // far faces of the groups' cuboids: their candidate bits, and the ray parameter in front of which none of them can be hit
@@ -1027,6 +1048,10 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     // loop of its own in which every lane runs the same code: sphere slots; triangle slots; the far faces of the
     // rotated groups' cuboids, and those only for rays whose closest hit so far is not already in front of them
     // (flat_cuboid_shared(): a ray that crosses a box meets two of its faces, the far one to no purpose).
+    far |= far0;
+#ifdef CRT_DEBUG_FAR
+    if (blockIdx.x == 0 && threadIdx.x < 8) printf("lane %d cand %x far %x far0 %x wf %x safe0 %g safe1 %g safe2 %g inv %g %g %g\n", (int)threadIdx.x, cand_lo, far, far0, world_faces, safe0, safe1, safe2, inv0.x, inv0.y, inv0.z);
+#endif
     far &= cand_lo;
     cand_lo ^= far;
 #if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
@@ -1062,18 +1087,15 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         if constexpr ((FEAT & kFeatWide) != 0 || (CRT_NO_SPHERE_PHASE && (FEAT & kFeatSphere) != 0)) test_slot(bit, SlotKind<kSlotAny>());
         else test_slot(bit, SlotKind<kSlotTri>());
     };
-    if constexpr (GROUPS == 0) {
-        while (cand_lo | cand_hi) next_slot();
-    } else {
-        while (cand_lo | cand_hi | far) {
-            if (cand_lo == 0u && far != 0u) {
-                if (best.t < safe1) far &= ~faces1;
-                if (GROUPS >= 2 && best.t < safe2) far &= ~faces2;
-                cand_lo = far;
-                far = 0u;
-            }
-            if (cand_lo | cand_hi) next_slot();
+    while (cand_lo | cand_hi | far) {
+        if (cand_lo == 0u && far != 0u) {
+            if (best.t < safe0) far &= ~world_faces;
+            if (GROUPS >= 1 && best.t < safe1) far &= ~faces1;
+            if (GROUPS >= 2 && best.t < safe2) far &= ~faces2;
+            cand_lo = far;
+            far = 0u;
         }
+        if (cand_lo | cand_hi) next_slot();
     }
     return best;
 }

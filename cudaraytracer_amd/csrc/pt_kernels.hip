@@ -1106,6 +1106,7 @@ struct crt_scene {
     std::vector<void*> image_mem;
     DevScene dev = {};
     crt_render_info render = {};
+    float far_margin = 0.0f;         // flat mode: largest margin of a cuboid whose far faces are tested last (0: none)
     int stack_entries = 8;           // LDS rows of the traversal stack (8 or 12): one row of -1 and 7 or 11 entries
     int spill_entries = 0;           // entries beyond them, in global memory
     int spill_threads = 0;
@@ -1836,7 +1837,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     std::vector<int32_t> flat_ent_obj;
     int flat_groups = 0, flat_box_end[kMaxFlatGroups + 1] = {0, 0, 0}, flat_cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
     int flat_cuboid_quad0 = 0, flat_slot_count = 0, flat_far_shift[kMaxFlatGroups + 1] = {-1, -1, -1};
-    uint32_t flat_sphere_bits = 0;
+    float flat_far_margin = 0.0f;    // largest margin in use (crt_scene_describe)
+    uint32_t flat_sphere_bits = 0, flat_world_face_a[3] = {0, 0, 0}, flat_world_face_b[3] = {0, 0, 0};
     bool flat_slot_xf = false;       // some flat slot's primitives carry their own transform
     bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
     if (can_flat) {
@@ -1990,6 +1992,19 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                         }
                         if (!fits) best.faces = 0;
                     }
+                    // world group: face A of an axis is the lower one, face B the upper one (a lone face: by the side of
+                    // the outer interval it lies on), which is what tells a ray's near faces from its far ones
+                    if (best.faces >= 4 && best.group == 0) {
+                        for (int x = 0; x < 3; x++) {
+                            int& fa = best.face_slot[2 * x];
+                            int& fb = best.face_slot[2 * x + 1];
+                            auto mid = [&](int slot) { return 0.5 * ((double)slots[(size_t)slot].box[x] + slots[(size_t)slot].box[3 + x]); };
+                            const double outer_mid = 0.5 * ((double)best.outer[2 * x] + best.outer[2 * x + 1]);
+                            if (fa >= 0 && fb >= 0) { if (mid(fa) > mid(fb)) std::swap(fa, fb); }
+                            else if (fa >= 0 && mid(fa) > outer_mid) std::swap(fa, fb);
+                            else if (fb >= 0 && mid(fb) < outer_mid) std::swap(fa, fb);
+                        }
+                    }
                     if (best.faces >= 4) {                                        // below that the shared part costs more than it saves
                         for (int k = 0; k < 6; k++) if (best.face_slot[k] >= 0) in_cuboid[(size_t)best.face_slot[k]] = 1;
                         cuboids.push_back(best);
@@ -2001,6 +2016,35 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             std::vector<float> cuboid_rec;
             int box_end[kMaxFlatGroups + 1] = {0, 0, 0}, cuboid_end[kMaxFlatGroups + 1] = {0, 0, 0};
             int far_cuboid_last_slot[kMaxFlatGroups + 1] = {-1, -1, -1};
+            int world_face_slot[6] = {-1, -1, -1, -1, -1, -1};           // faces of the world group's last cuboid, if its far faces wait
+            // the world group's largest cuboid (a room) last: the last one is the one whose far faces wait
+            std::stable_sort(cuboids.begin(), cuboids.end(), [](const Cuboid& a, const Cuboid& b) {
+                auto volume = [](const Cuboid& c) { return (double)(c.outer[1] - c.outer[0]) * (c.outer[3] - c.outer[2]) * (c.outer[5] - c.outer[4]); };
+                if (a.group != b.group) return a.group < b.group;
+                return a.group == 0 && volume(a) < volume(b);
+            });
+            // hit_tri's rounding bound per cuboid (see the rotated groups below): 1024 x 20 x 2^-24 x reach / sine of the
+            // sharpest angle between two triangle edges, at most an eighth of the cuboid's thinnest side; +inf = not in use
+            auto far_margin = [&](const Cuboid& cu, float thinnest) {
+                double sine = 1.0;
+                for (int k = 0; k < 6; k++) {
+                    if (cu.face_slot[k] < 0) continue;
+                    const Slot& sl = slots[(size_t)cu.face_slot[k]];
+                    if (sl.type != CRT_OBJ_TRI) return INFINITY;
+                    for (int which = 0; which < (sl.has_b ? 2 : 1); which++) {
+                        const crt_object& t = d->objects[flat_ent_obj[which ? sl.rank_b : sl.rank_a]];
+                        const V3 e1 = v3(t.p1), e2 = v3(t.p2);
+                        const double area = length(cross(e1, e2)), sides = (double)length(e1) * length(e2);
+                        sine = std::fmin(sine, sides > 0.0 ? area / sides : 0.0);
+                    }
+                }
+                const double m = 0x1p-14 * scene_reach(d) / sine;
+                if (!(opt.flat_cuboids != 3 && sine > 0.0 && std::isfinite(m) && m <= 0.125 * thinnest)) return INFINITY;
+                flat_far_margin = std::fmax(flat_far_margin, (float)m);
+                return (float)m;
+            };
+            int world_cuboids_left = 0;
+            for (const Cuboid& cu : cuboids) world_cuboids_left += cu.group == 0;
             for (int g = 0; g <= kMaxFlatGroups; g++) {
                 for (const Cuboid& cu : cuboids) {
                     if (cu.group != g) continue;
@@ -2015,9 +2059,20 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                     if (g == 0) {                                                 // flat_cuboid(): every face keeps its own interval
                         for (int k = 0; k < 6; k++) rec[k] = cu.outer[k];
                         for (int k = 0; k < 6; k++) {
-                            if (cu.face_slot[k] < 0) continue;
+                            // (an absent face: the plane that would face the ray's origin at infinity, see flat_cuboid())
+                            if (cu.face_slot[k] < 0) { rec[8 + 2 * k] = rec[8 + 2 * k + 1] = (k & 1) ? INFINITY : -INFINITY; continue; }
                             const Slot& sl = slots[(size_t)cu.face_slot[k]];
                             rec[8 + 2 * k] = sl.box[k / 2]; rec[8 + 2 * k + 1] = sl.box[3 + k / 2];
+                        }
+                        // the far faces of the last (largest) cuboid wait for the other candidates, like those of the rotated groups' cuboids
+                        rec[7] = INFINITY;
+                        if (--world_cuboids_left == 0) {
+                            const float thinnest = std::fmin(cu.outer[1] - cu.outer[0], std::fmin(cu.outer[3] - cu.outer[2], cu.outer[5] - cu.outer[4]));
+                            rec[7] = far_margin(cu, thinnest);
+                            if (std::isfinite(rec[7])) {
+                                int at = (int)ordered_slots.size() - cu.faces;
+                                for (int k = 0; k < 6; k++) if (cu.face_slot[k] >= 0) world_face_slot[k] = at++;
+                            }
                         }
                         cuboid_rec.insert(cuboid_rec.end(), rec, rec + 20);
                     } else {                                                      // flat_cuboid_shared(): four planes per axis
@@ -2032,24 +2087,9 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
                         // Far faces wait for the near ones (flat_cuboid_shared()) in a group's last cuboid when it has all
                         // six faces.  The margin: hit_tri's t, measured along a face's axis, is off by at most about
                         // 20 x 2^-24 x reach / sin(angle between the triangle's edges), reach = the largest distance
-                        // between a ray origin and a point of the scene; 1024 times that bound, and no more than an
-                        // eighth of the cuboid's thinnest side (else the faces are simply all tested).
-                        float margin = INFINITY;
+                        // between a ray origin and a point of the scene (far_margin() above).
                         far_cuboid_last_slot[g] = -1;                             // (the group's LAST cuboid is the one: its distance is what the box phase hands on)
-                        if (present == 63) {
-                            double sine = 1.0;
-                            for (int k = 0; k < 6; k++) {
-                                const Slot& sl = slots[(size_t)cu.face_slot[k]];
-                                for (int which = 0; which < (sl.has_b ? 2 : 1); which++) {
-                                    const crt_object& t = d->objects[flat_ent_obj[which ? sl.rank_b : sl.rank_a]];
-                                    const V3 e1 = v3(t.p1), e2 = v3(t.p2);
-                                    const double area = length(cross(e1, e2)), sides = (double)length(e1) * length(e2);
-                                    sine = std::fmin(sine, sides > 0.0 ? area / sides : 0.0);
-                                }
-                            }
-                            const double m = 0x1p-14 * scene_reach(d) / sine;
-                            if (sine > 0.0 && std::isfinite(m) && m <= 0.125 * thinnest) margin = (float)m;
-                        }
+                        const float margin = present == 63 ? far_margin(cu, thinnest) : INFINITY;
                         rec[14] = margin;
                         if (std::isfinite(margin)) far_cuboid_last_slot[g] = (int)ordered_slots.size() - 1;   // its face zB
                         cuboid_rec.insert(cuboid_rec.end(), rec, rec + 16);
@@ -2074,6 +2114,10 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             for (int g = 1; g <= kMaxFlatGroups; g++) {
                 const int bit = far_cuboid_last_slot[g] < 0 ? -1 : flat_slot_count - 1 - far_cuboid_last_slot[g];
                 flat_far_shift[g] = (bit >= 0 && bit + 6 <= 32 && opt.flat_cuboids != 3) ? bit : -1;
+            }
+            for (int k = 0; k < 6; k++) {
+                const int bit = world_face_slot[k] < 0 ? -1 : flat_slot_count - 1 - world_face_slot[k];
+                if (bit >= 0 && bit < 32) (k & 1 ? flat_world_face_b : flat_world_face_a)[k / 2] = 1u << bit;
             }
             for (int s = 0; s < flat_slot_count; s++)
                 if (ordered_slots[(size_t)s].type != CRT_OBJ_TRI && flat_slot_count - 1 - s < 32) flat_sphere_bits |= 1u << (flat_slot_count - 1 - s);
@@ -2224,6 +2268,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     sc->flat.cuboid_quad0 = flat_cuboid_quad0;
     sc->flat.groups = flat_groups;
     sc->flat.sphere_bits = flat_sphere_bits;
+    sc->far_margin = flat_far_margin;
+    for (int a = 0; a < 3; a++) { sc->flat.world_face_a[a] = flat_world_face_a[a]; sc->flat.world_face_b[a] = flat_world_face_b[a]; }
     for (int g = 0; g <= kMaxFlatGroups; g++) sc->flat.far_shift[g] = flat_far_shift[g];
     sc->lds_flat_bytes = (int)((size_t)sc->flat.slot_count * kSlotQuads * 16 + xforms.size() * 4);
     sc->mode = opt.mode;
@@ -2298,8 +2344,12 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
     char line[256];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%03x slots=%d cuboids=%d groups=%d reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
-                                sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
+    // far=: candidate bits of the cuboid faces that are tested last (world group, rotated groups 1 and 2)
+    unsigned world_far = 0;
+    for (int a = 0; a < 3; a++) world_far |= sc->flat.world_face_a[a] | sc->flat.world_face_b[a];
+    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%03x slots=%d cuboids=%d groups=%d far=%x/%x/%x margin=%g reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
+                                sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, world_far, sc->flat.far_shift[1] >= 0 ? 63u << sc->flat.far_shift[1] : 0u,
+                                sc->flat.far_shift[2] >= 0 ? 63u << sc->flat.far_shift[2] : 0u, (double)sc->far_margin, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
                                 sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
                                 sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");
     if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);
