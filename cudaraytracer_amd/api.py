@@ -160,7 +160,7 @@ class Scene:
     # device side -----------------------------------------------------------------------
     def set_options(self, **options):
         """Options of the device copy (fields of crt_scene_options: accel, mode, ieee_division,
-        work_items, blocks, ready_percent, prim_batch, deterministic); drops the device copy."""
+        work_items, blocks, ready_percent, prim_batch, deterministic, exact_ties, ...); drops the device copy."""
         unknown = set(options) - {name for name, _ in _capi.crt_scene_options._fields_ if name != "struct_size"}
         if unknown:
             raise TypeError(f"unknown scene option(s): {sorted(unknown)}")

@@ -123,6 +123,7 @@ enum : int {
     kFeatCamera = 1 << 7,       // orthographic camera, defocus blur, moving spheres (ray time)
     kFeatXform = 1 << 8,        // objects under a transform (rotate / translate wrappers)
     kFeatAll = 0x1ff,
+    kFeatExactTies = 1 << 9,    // tree walks only, on request: near-ties decided the way the reference's ordered walk decides them (consider_exact())
     kFeatBasic = 0,             // untransformed flat triangles under diffuse materials and lights of one colour, pinhole camera
     kFeatBasicXform = kFeatXform   // the same with transformed objects (rotated boxes)
 };
@@ -456,6 +457,28 @@ __device__ __forceinline__ void consider(Hit& best, bool& best_tri, float& best_
     }
 }
 
+// The same decision for a walk that has to agree with the reference's ordered walk (bvh.cuh:387-419) even where a hit
+// lies, by rounding, just in front of its own box.  The reference meets its candidates in rank order and tests one
+// only if its box is hit on [tmin, closest so far]; so of two candidates the later-ranked one counts iff its box
+// entry does not lie beyond the earlier one's t AND its own t does not (triangle: closed interval, sphere: open).
+// X against the best so far B, in either order of arrival:
+//   X ranked after B:   X replaces B iff lo_X <= t_B and t_X <= t_B (sphere: <);
+//   X ranked before B:  B would have replaced X iff lo_B <= t_X and t_B <= t_X (sphere B: <); else X stands.
+// The walk culls boxes and primitives against the closest hit times (1 + 2^-12), so that both of two near-tied
+// candidates reach this decision.  (Chains of three candidates within rounding of each other are not modelled.)
+__device__ __forceinline__ void consider_exact(Hit& best, bool& best_tri, float& best_lo, bool ok, float t, float lo, int rank, bool is_tri, float bu, float bv) {
+    const bool x_after = lo <= best.t && (is_tri ? t <= best.t : t < best.t);
+    const bool b_stays = best_lo <= t && (best_tri ? best.t <= t : best.t < t);
+    const bool take = best.obj < 0 ? true : (rank > best.obj ? x_after : !b_stays);
+    if (ok && take) {
+        best.t = t; best.obj = rank; best.bu = bu; best.bv = bv; best_lo = lo;
+        best_tri = is_tri;
+    }
+}
+// Upper end of the ray interval boxes and primitives are culled against.
+template <int FEAT>
+__device__ __forceinline__ float cull_distance(float closest) { return (FEAT & kFeatExactTies) ? closest * 1.000244140625f : closest; }
+
 // Closest hit over the flat BVH4, resumable.
 //
 // The walk differs from bvh.cuh:387-419 in the ORDER nodes are visited (children nearest along
@@ -507,14 +530,16 @@ __device__ __forceinline__ void tree_prim(const Mem& S, int obj, float lo, const
     const int before = ts.best.obj;
     if (!(FEAT & kFeatSphere) || type == 2) {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
-        const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, ts.best.t, FAST, t, bu, bv);
-        consider<!(FEAT & kFeatSphere)>(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, true, bu, bv);
+        const bool ok = tri_test(o, d, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), v3(q1.z, q1.w, q2.x), tmin, cull_distance<FEAT>(ts.best.t), FAST, t, bu, bv);
+        if constexpr ((FEAT & kFeatExactTies) != 0) consider_exact(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, true, bu, bv);
+        else consider<!(FEAT & kFeatSphere)>(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, true, bu, bv);
     } else {
         // the root the reference would take does not depend on the interval's upper end: the
         // near root if it is beyond tmin, else the far one (hittable.cuh:283-289)
         float t = 0.0f;
         const bool ok = sphere_test<FAST>(o, d, r.time, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), q0.w, tmin, INFINITY, t);
-        consider(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, false, 0.0f, 0.0f);
+        if constexpr ((FEAT & kFeatExactTies) != 0) consider_exact(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, false, 0.0f, 0.0f);
+        else consider(ts.best, ts.best_tri, ts.best_lo, ok, t, lo, rank, false, 0.0f, 0.0f);
     }
     if (ts.best.obj != before) ts.best_obj = obj;
 }
@@ -578,10 +603,11 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
             const int codes[4] = {__float_as_int(codef.x), __float_as_int(codef.y), __float_as_int(codef.z), __float_as_int(codef.w)};
             float los[4];
             unsigned hit_mask = 0;                                  // bit i: the ray meets slot i's box before the closest hit so far
+            const float closest = cull_distance<FEAT>(ts.best.t);
 #pragma unroll
             for (int i = 3; i >= 0; i--) {
                 float t0 = (nxs[i] - r.o.x) * ix, t1 = (fxs[i] - r.o.x) * ix;
-                float lo = fmaxf(tmin, t0), hi = fminf(ts.best.t, t1);
+                float lo = fmaxf(tmin, t0), hi = fminf(closest, t1);
                 t0 = (nys[i] - r.o.y) * iy; t1 = (fys[i] - r.o.y) * iy;
                 lo = fmaxf(lo, t0); hi = fminf(hi, t1);
                 t0 = (nzs[i] - r.o.z) * iz; t1 = (fzs[i] - r.o.z) * iz;
@@ -640,7 +666,7 @@ __device__ __forceinline__ void tree_run(const Mem& S, const Ray& r, float tmin,
                 const int code = stk.code[i * stk.stride];
                 const float lo = stk.entry[i * stk.stride];
                 // an earlier candidate may have shrunk the interval below this box's entry
-                if (!(ts.best.t < lo)) {
+                if (!(cull_distance<FEAT>(ts.best.t) < lo)) {
                     CRT_PROF(kProfPrim);
                     tree_prim<FAST, FEAT>(S, code, lo, r, tmin, ts);
                 }

@@ -1284,6 +1284,7 @@ int launch_tree_feat(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
 template <int STACK, int FAST>
 int launch_tree(crt_scene* sc, const RenderArgs& A, dim3 grid, int mode) {
     if (variant_features(sc) == kFeatBasic) return launch_tree_feat<STACK, FAST, kFeatBasic>(sc, A, grid, mode);
+    if (variant_features(sc) & kFeatExactTies) return launch_tree_feat<STACK, FAST, kFeatAll | kFeatExactTies>(sc, A, grid, mode);
     return launch_tree_feat<STACK, FAST, kFeatAll>(sc, A, grid, mode);
 }
 
@@ -1299,6 +1300,7 @@ int variant_features(const crt_scene* sc) {
         return (sc->features & kFeatWide) ? kFeatAll : (kFeatAll & ~kFeatWide);
     }
     // the flat mode's feature bits say nothing about a tree walk
+    if (sc->opt.exact_ties) return kFeatAll | kFeatExactTies;
     return (sc->features & ~(kFeatSlotXf | kFeatWide)) == 0 ? kFeatBasic : kFeatAll;
 }
 template <int GROUPS>
@@ -1651,6 +1653,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     if (opt.general_kernel < 0 || opt.general_kernel > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->general_kernel must be 0 or 1");
     if (opt.flat_cuboids < 0 || opt.flat_cuboids > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..3");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
+    if (opt.exact_ties < 0 || opt.exact_ties > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->exact_ties must be 0 or 1");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
         return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
     int bvh_depth = 0;
@@ -1840,7 +1843,9 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     float flat_far_margin = 0.0f;    // largest margin in use (crt_scene_describe)
     uint32_t flat_sphere_bits = 0, flat_world_face_a[3] = {0, 0, 0}, flat_world_face_b[3] = {0, 0, 0};
     bool flat_slot_xf = false;       // some flat slot's primitives carry their own transform
-    bool can_flat = !ordered && !leaf_slots.empty() && leaf_slots.size() <= 64;     // the flat mode tests in no particular order
+    // the flat mode tests in no particular order and keeps no box entry distances: not for scenes that have to be walked
+    // in the reference's order, nor where near-ties are to be decided like the reference's ordered walk decides them
+    bool can_flat = !ordered && !opt.exact_ties && !leaf_slots.empty() && leaf_slots.size() <= 64;
     if (can_flat) {
         struct Slot {
             int group, xf, type, rank_a, rank_b;

@@ -208,6 +208,15 @@ typedef struct crt_scene_options {
     int32_t general_kernel;   /* 1: always run the kernel variant compiled for every scene feature (spheres, textures,
                                  metal and glass, camera kinds ...) instead of the one compiled for just what the
                                  scene contains; same results, for comparison                         */
+    int32_t exact_ties;       /* 1: two hits whose ray parameters differ in the last bits are told apart the way the
+                                 reference's ordered walk does it (bvh.cuh:398-411: a candidate counts only if its BOX is
+                                 still hit on [t_min, closest so far], which fails for a hit that rounding puts just in
+                                 front of its own box): boxes and primitives are culled against the closest hit times
+                                 (1 + 2^-12) and the two candidates are compared with both box entry distances.  BVH4
+                                 walk only (the small-scene mode keeps no entry distances and is not used); a few
+                                 percent slower.  0 (default): the nearer hit wins, exact ties by visiting rank; differs
+                                 from the reference in about one path in 10^8 (a ray through an edge that lies in a
+                                 box face)                                                             */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 
