@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/crt.h"
+#include "../../include/crt_dev.h"
 #include "host_box.h"
 
 namespace crt {
@@ -30,6 +31,12 @@ struct AccelNode {
 void build_accel(const crt_bvh4& ref, std::vector<AccelNode>& nodes, int& depth);
 // The reference BVH4 itself in that form.
 void accel_from_reference(const crt_bvh4& ref, std::vector<AccelNode>& nodes);
+
+// BMP and TGA (bmp_tga_decode.cpp): what stb_image v2.30 returns for the same file; `ch` = the file's own channel count
+bool looks_like_bmp(const std::vector<uint8_t>& file);
+bool decode_bmp(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::vector<uint8_t>& out, std::string& err);
+bool looks_like_tga(const std::vector<uint8_t>& file);
+bool decode_tga(const std::vector<uint8_t>& file, int& w, int& h, int& ch, std::vector<uint8_t>& out, std::string& err);
 
 // Image decoding for `type: image` textures. Returns true on success; pixels has
 // width*height*channels bytes, channels in {1,3,4}.

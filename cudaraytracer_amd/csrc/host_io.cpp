@@ -448,7 +448,14 @@ bool load_image_file(const std::string& path, float hdr_gamma, float hdr_scale, 
     else if (file.size() >= 6 && (!std::memcmp(file.data(), "#?RADIANCE", std::min<size_t>(10, file.size())) || !std::memcmp(file.data(), "#?RGBE", 6)))
         ok = decode_hdr(file, hdr_gamma, hdr_scale, width, height, channels, pixels, error);
     else if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) ok = decode_pnm(file, width, height, channels, pixels, error);
-    else { error = "no built-in decoder for this file type (PNG, JPEG, Radiance HDR and binary PGM/PPM are built in; stb_image's BMP, TGA, GIF, PSD and PIC are not: install a decoder with crt_set_image_loader)"; return false; }
+    else if (looks_like_bmp(file)) ok = decode_bmp(file, width, height, channels, pixels, error);
+    // stb_image's GIF, PSD and PIC readers have signatures too: named here so that such a file is not taken for a TGA
+    else if (file.size() >= 4 && (!std::memcmp(file.data(), "GIF8", 4) || !std::memcmp(file.data(), "8BPS", 4) || !std::memcmp(file.data(), "\x53\x80\xF6\x34", 4))) {
+        error = "no built-in decoder for GIF, PSD or PIC files (PNG, JPEG, BMP, TGA, Radiance HDR and binary PGM/PPM are built in): install a decoder with crt_set_image_loader";
+        return false;
+    }
+    else if (looks_like_tga(file)) ok = decode_tga(file, width, height, channels, pixels, error);       // no signature: tested last, like stb_image does
+    else { error = "no built-in decoder for this file type (PNG, JPEG, BMP, TGA, Radiance HDR and binary PGM/PPM are built in; stb_image's GIF, PSD and PIC are not: install a decoder with crt_set_image_loader)"; return false; }
     if (!ok) return false;
     if (desired_channels >= 1 && desired_channels <= 4 && desired_channels != channels) {
         convert_channels(pixels, width, height, channels, desired_channels);

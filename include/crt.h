@@ -188,33 +188,21 @@ typedef struct crt_scene_options {
     int32_t accel;            /* CRT_ACCEL_*                                                   */
     int32_t mode;             /* initial geometry access mode, see crt_scene_set_mode          */
     int32_t ieee_division;    /* 1: never use the Newton-refined reciprocal                    */
-    int32_t work_items;       /* work items (pixel tile x sample chunk) a frame is cut into; 0 = 65536 */
-    int32_t blocks;           /* workgroups of the persistent render kernel; 0 = fill the GPU  */
-    int32_t ready_percent;    /* tree walk: shade once this share of a wave's rays is done; 0 = 65 (45 for hierarchies beyond 4 MB) */
-    int32_t prim_batch;       /* tree walk: lanes with leaf candidates that start a test round; 0 = 8 (2 or 16 for hierarchies beyond 4 MB) */
+    /* Tuning and comparison knobs (0 = the library's choice), described in crt_dev.h: */
+    int32_t work_items, blocks, ready_percent, prim_batch;
     int32_t deterministic;    /* 1: one sample per chunk, so every pixel sum is added in sample order and
                                  a render is bit-reproducible from run to run (costs 56 B of scratch per
                                  pixel AND sample instead of per pixel and chunk; a call may then render
                                  at most samples_per_pixel samples)                              */
-    int32_t wavefront;        /* BVH walk in HBM: 1 = wavefront pipeline (path state in HBM, one trace and one shade
-                                 kernel per bounce, per-path result records: bulk renders reproducible bit for bit;
-                                 measured slower than the fused kernel), 0 or 2 = the fused kernel (default) */
-    int32_t wavefront_paths;  /* path slots (224 bytes each) of the wavefront buffers; 0 = 67 108 864   */
-    int32_t flat_cuboids;     /* small scenes: 0 or 1 = slots whose boxes share planes like the faces of an axis-aligned
-                                 box (a box object, the walls of a room) are box-tested together (default; same
-                                 candidates, fewer operations), 2 = every slot on its own, 3 = together, but the far
-                                 faces of a rotated box are tested with its near ones instead of after them and only
-                                 where the closest hit is not already in front of them (same hits, for comparison) */
-    int32_t general_kernel;   /* 1: always run the kernel variant compiled for every scene feature (spheres, textures,
-                                 metal and glass, camera kinds ...) instead of the one compiled for just what the
-                                 scene contains; same results, for comparison                         */
+    /* Development and comparison switches (0 = default), described in crt_dev.h: */
+    int32_t wavefront, wavefront_paths, flat_cuboids, general_kernel;
     int32_t exact_ties;       /* 1: two hits whose ray parameters differ in the last bits are told apart the way the
                                  reference's ordered walk does it (bvh.cuh:398-411: a candidate counts only if its BOX is
                                  still hit on [t_min, closest so far], which fails for a hit that rounding puts just in
                                  front of its own box): boxes and primitives are culled against the closest hit times
                                  (1 + 2^-12) and the two candidates are compared with both box entry distances.  BVH4
-                                 walk only (the small-scene mode keeps no entry distances and is not used); a few
-                                 percent slower.  0 (default): the nearer hit wins, exact ties by visiting rank; differs
+                                 walk only (the small-scene mode keeps no entry distances and is not used); about a
+                                 tenth slower.  0 (default): the nearer hit wins, exact ties by visiting rank; differs
                                  from the reference in about one path in 10^8 (a ray through an edge that lies in a
                                  box face)                                                             */
 } crt_scene_options;
@@ -310,13 +298,6 @@ void* crt_scene_stream(crt_scene* sc);
  * kernel(s) and the pass-resolve kernel, in milliseconds. */
 int crt_render_timings(crt_scene* sc, float* trace_ms, float* resolve_ms);
 
-/* Development aid: loop-occupancy counters of a library built with -DCRT_PROFILE
- * (128 values: site k < 8 -> [2k] wave-level executions, [2k+1] active lanes; flat mode: [16+n] rays
- * with n candidate slots (7 = seven or more), [24+n] waves whose fullest lane held n, [64+b] how
- * often candidate bit b was set in a lane with three or more; [32+s] shader clocks the waves spent
- * in section s of the path loop).  The product build returns CRT_ERR_UNSUPPORTED. */
-int crt_profile_counters(uint64_t* out128, int reset);
-
 /* How the kernels reach the geometry: 0 = automatic (default), 1 = BVH4 walk with the scene in
  * HBM, 2 = BVH4 walk over an LDS copy of the scene (small scenes), 3 = flat box loop with a
  * per-lane candidate mask (at most 64 objects).  A mode the scene does not qualify for falls
@@ -331,25 +312,6 @@ int crt_scene_set_mode(crt_scene* sc, int mode);
  * in exactly that order; order=free: any order gives the same image and the library picks its own.
  * Writes at most `size` bytes including the terminator; returns the full length. */
 int crt_scene_describe(crt_scene* sc, char* text, int size);
-
-/* Primary-ray probe used by the parity tests: for every pixel trace the camera ray of
- * sample number `sample` (1-based, as in render.cuh:128) and return the closest hit of
- * bounce 0: object index (-1 = miss), ray parameter t, surface u, v, front_face.
- * Host output arrays of W*H entries each (any may be NULL). */
-int crt_trace_primary(crt_scene* sc, int sample, int32_t* object_index, float* t, float* u,
-                      float* v, int32_t* front_face);
-
-/* Single-function probes used by the known-answer tests: `count` cases of ONE building block of
- * the path, evaluated on the device by the functions the render kernels call.  Host arrays;
- * integers travel as float bit patterns.
- *   CRT_PROBE_BOX      aabb::hit (aabb.cuh:132-156)  in[14] = min[3] max[3] origin[3] dir[3] tmin tmax
- *                      out[1]: bit 0 = the tree walk's form of the test, bit 1 = the flat mode's (tmax ignored)
- *   CRT_PROBE_OBJECT   hittable::hit (hittable.cuh:426-446)  in[10] = object origin[3] dir[3] time tmin tmax
- *                      out[11] = hit t u v front_face normal[3] p[3]   (normal after the normal map)
- *   CRT_PROBE_TEXTURE  _texture::value (texture.cuh:313-324)  in[6] = texture u v p[3]   out[3] = colour
- *   CRT_PROBE_CAMERA   camera::get_ray (camera.cuh:269-278)   in[3] = i j sample         out[7] = origin[3] dir[3] time */
-enum { CRT_PROBE_BOX = 0, CRT_PROBE_OBJECT = 1, CRT_PROBE_TEXTURE = 2, CRT_PROBE_CAMERA = 3 };
-int crt_probe(crt_scene* sc, int kind, int count, const float* in, float* out);
 
 /* save_passes() (buffer.cuh:165-195): normalise the passes to 8 bit exactly like
  * normalize_* (buffer.cuh:202-318) from HOST float arrays.  `out` = W*H*3 bytes.

@@ -1,4 +1,5 @@
-"""The C-ABI library loads on a machine without a GPU and exports every symbol include/crt.h declares."""
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/crt.h (the drop-in
+for the reference's render()) and include/crt_dev.h (probes and counters for tests and profiling) declare."""
 import ctypes
 import os
 import re
@@ -6,12 +7,22 @@ import re
 from conftest import ROOT
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "crt.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)
+def declared_functions(headers=("crt.h", "crt_dev.h")):
+    names = []
+    for header in headers:
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)
     # typedef'd function pointer type is not a symbol
     return sorted(set(n for n in names if n != "crt_image_loader_fn"))
+
+
+def test_probes_and_counters_live_in_the_development_header():
+    product = declared_functions(("crt.h",))
+    for name in ("crt_probe", "crt_trace_primary", "crt_profile_counters"):
+        assert name not in product and name in declared_functions(("crt_dev.h",))
+    for name in ("crt_render", "crt_render_static", "crt_render_range", "crt_render_bands", "crt_scene_create", "crt_buffers_create"):
+        assert name in product
 
 
 def test_every_declared_symbol_is_exported():

@@ -251,6 +251,146 @@ def test_hostile_headers_are_rejected_without_allocating(crt, tmp_path):
     Image.fromarray(img, "RGB").save(tmp_path / "real.png")
     os.rename(tmp_path / "real.png", tmp_path / "texture.tex")
     assert np.array_equal(crt.load_image(str(tmp_path / "texture.tex")), img)
-    (tmp_path / "unknown.bmp").write_bytes(b"BM" + b"\0" * 60)
-    with pytest.raises(crt.CrtError, match="BMP, TGA, GIF, PSD"):
+    (tmp_path / "unknown.bmp").write_bytes(b"BM" + b"\0" * 60)          # "BM" without a known header size, and no TGA either
+    with pytest.raises(crt.CrtError, match="GIF, PSD and PIC are not"):
         crt.load_image(str(tmp_path / "unknown.bmp"))
+    (tmp_path / "anim.gif").write_bytes(b"GIF89a" + b"\1" * 60)
+    with pytest.raises(crt.CrtError, match="no built-in decoder for GIF, PSD or PIC"):
+        crt.load_image(str(tmp_path / "anim.gif"))
+
+
+# ---------------------------------------------------------------------------- BMP and TGA ----
+# Both formats are lossless, so an independent decoder (Pillow) has to agree in every byte wherever the two
+# libraries mean the same thing; stb_image's own conventions (what the reference's stbi_load returns,
+# stb_image.h:5531-5732 and :5871-6074) are pinned on hand-made files.
+def _bmp(width, height, bpp, rows, palette=b"", compress=0, masks=b"", header=40, top_down=False):
+    """A BMP file from raw row bytes (padded here to 4 bytes)."""
+    import struct
+    body = b"".join(r + b"\0" * ((-len(r)) & 3) for r in rows)
+    info = struct.pack("<IiiHHIIiiII", header, width, -height if top_down else height, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+    info += b"\0" * (header - 40) if header in (40, 56) else b""
+    offset = 14 + len(info) + len(masks) + len(palette)
+    return b"BM" + struct.pack("<IHHI", offset + len(body), 0, 0, offset) + info + masks + palette + body
+
+
+def test_bmp_equal_to_independent_decoder(crt, tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(5)
+    for size in ((7, 5), (8, 8), (33, 2), (1, 1)):
+        rgb = g.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8)
+        for mode, name in (("RGB", "rgb.bmp"), ("L", "grey.bmp"), ("P", "pal.bmp"), ("1", "mono.bmp"), ("RGBA", "rgba.bmp")):
+            im = Image.fromarray(rgb, "RGB").convert(mode) if mode != "P" else Image.fromarray(rgb, "RGB").quantize(16)
+            path = str(tmp_path / name)
+            im.save(path)
+            got = crt.load_image(path)
+            want = np.asarray(Image.open(path).convert("RGBA" if mode == "RGBA" else "RGB"), dtype=np.uint8)
+            assert got.shape == want.shape and np.array_equal(got, want), (size, mode)
+            # channel requests go through the same conversion as for every other format
+            assert crt.load_image(path, desired_channels=4).shape[2] == 4
+            assert np.array_equal(crt.load_image(path, flip_y=True), got[::-1])
+
+
+def test_bmp_conventions_of_stb_image(crt, tmp_path):
+    import struct
+    # 4 bits per pixel, odd width: high nibble first, rows bottom-up, padded to 4 bytes
+    pal = bytes([10, 20, 30, 0, 40, 50, 60, 0, 70, 80, 90, 0])              # blue, green, red, unused
+    (tmp_path / "p4.bmp").write_bytes(_bmp(3, 2, 4, [bytes([0x01, 0x20]), bytes([0x21, 0x00])], palette=pal))
+    got = crt.load_image(str(tmp_path / "p4.bmp"))
+    colours = np.array([[30, 20, 10], [60, 50, 40], [90, 80, 70]], np.uint8)
+    assert np.array_equal(got, colours[np.array([[2, 1, 0], [0, 1, 2]])])    # (file's first row is the image's last)
+    # the same file with a negative height is stored top-down
+    (tmp_path / "p4t.bmp").write_bytes(_bmp(3, 2, 4, [bytes([0x01, 0x20]), bytes([0x21, 0x00])], palette=pal, top_down=True))
+    assert np.array_equal(crt.load_image(str(tmp_path / "p4t.bmp")), got[::-1])
+    # 16 bits without masks: 5-5-5, each channel widened by repeating its bits (31 -> 255, 1 -> 8, 30 -> 247)
+    px = struct.pack("<HH", (31 << 10) | (1 << 5) | 30, (16 << 10) | 0 | 0)
+    (tmp_path / "r555.bmp").write_bytes(_bmp(2, 1, 16, [px]))
+    assert crt.load_image(str(tmp_path / "r555.bmp")).tolist() == [[[255, 8, 247], [132, 0, 0]]]
+    # 16 bits with 5-6-5 masks (a 6-bit channel: 63 -> 255, 1 -> 4)
+    masks = struct.pack("<III", 0xF800, 0x07E0, 0x001F)
+    px = struct.pack("<HH", (31 << 11) | (1 << 5) | 0, (0 << 11) | (63 << 5) | 31)
+    (tmp_path / "r565.bmp").write_bytes(_bmp(2, 1, 16, [px], compress=3, masks=masks))
+    assert crt.load_image(str(tmp_path / "r565.bmp")).tolist() == [[[255, 4, 0], [0, 255, 255]]]
+    # 32 bits: four channels; alpha bytes that are ALL zero mean "no alpha" (opaque), any other value is kept
+    (tmp_path / "a0.bmp").write_bytes(_bmp(2, 1, 32, [bytes([1, 2, 3, 0, 4, 5, 6, 0])]))
+    assert crt.load_image(str(tmp_path / "a0.bmp")).tolist() == [[[3, 2, 1, 255], [6, 5, 4, 255]]]
+    (tmp_path / "a1.bmp").write_bytes(_bmp(2, 1, 32, [bytes([1, 2, 3, 0, 4, 5, 6, 9])]))
+    assert crt.load_image(str(tmp_path / "a1.bmp")).tolist() == [[[3, 2, 1, 0], [6, 5, 4, 9]]]
+    # run-length BMPs are refused like stb_image refuses them; so are truncated headers and absurd sizes
+    for name, data in {"rle.bmp": _bmp(2, 1, 8, [b"\0\0"], palette=b"\0" * 8, compress=1),
+                       "huge.bmp": _bmp(2000000000, 2000000000, 24, [b""]),
+                       "masks.bmp": _bmp(2, 1, 16, [b"\0" * 4], compress=3, masks=struct.pack("<III", 7, 7, 7)),
+                       "offset.bmp": _bmp(2, 1, 24, [b"\0" * 6])[:10] + struct.pack("<I", 5) + _bmp(2, 1, 24, [b"\0" * 6])[14:]}.items():
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(crt.CrtError):
+            crt.load_image(str(tmp_path / name))
+
+
+def _tga(width, height, bits, data, image_type=2, descriptor=0, colour_map=b"", map_len=0, map_bits=0, ident=b""):
+    import struct
+    return struct.pack("<BBBHHBHHHHBB", len(ident), 1 if colour_map else 0, image_type, 0, map_len, map_bits, 0, 0, width, height, bits, descriptor) + ident + colour_map + data
+
+
+def test_tga_equal_to_independent_decoder(crt, tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(6)
+    for size in ((7, 5), (16, 3), (1, 1), (130, 2)):
+        rgba = g.integers(0, 256, (size[1], size[0], 4), dtype=np.uint8)
+        rgba[:, : size[0] // 2] = rgba[:, :1]                                # runs, so that the run-length form has both packet kinds
+        for mode in ("RGB", "RGBA", "L", "P"):
+            for rle in (False, True):
+                im = Image.fromarray(rgba, "RGBA").convert(mode) if mode != "P" else Image.fromarray(rgba[:, :, :3].copy(), "RGB").quantize(32)
+                path = str(tmp_path / f"{mode}_{int(rle)}.tga")
+                im.save(path, compression="tga_rle" if rle else None)
+                got = crt.load_image(path)
+                want = np.asarray(Image.open(path).convert({"L": "L", "RGBA": "RGBA"}.get(mode, "RGB")), dtype=np.uint8)
+                want = want[:, :, None] if want.ndim == 2 else want
+                assert got.shape == want.shape and np.array_equal(got, want), (size, mode, rle)
+
+
+def test_tga_conventions_of_stb_image(crt, tmp_path):
+    import struct
+    # rows are stored bottom-up unless bit 5 of the descriptor is set; colour is stored blue first
+    data = bytes([1, 2, 3, 4, 5, 6])                                          # two pixels, one per row
+    (tmp_path / "up.tga").write_bytes(_tga(1, 2, 24, data))
+    (tmp_path / "down.tga").write_bytes(_tga(1, 2, 24, data, descriptor=0x20, ident=b"id!"))
+    assert crt.load_image(str(tmp_path / "up.tga")).tolist() == [[[6, 5, 4]], [[3, 2, 1]]]
+    assert crt.load_image(str(tmp_path / "down.tga")).tolist() == [[[3, 2, 1]], [[6, 5, 4]]]
+    # 16-bit colour: 5-5-5 scaled as c * 255 / 31 (30 -> 246, not the 247 of bit repetition), no alpha
+    px = struct.pack("<HH", (31 << 10) | (1 << 5) | 30, 0x8000 | (16 << 10))
+    (tmp_path / "c16.tga").write_bytes(_tga(2, 1, 16, px, descriptor=0x20))
+    assert crt.load_image(str(tmp_path / "c16.tga")).tolist() == [[[255, 8, 246], [131, 0, 0]]]
+    # 16-bit grey is two channels (grey, alpha): the scene loader refuses those like the reference does (texture.cuh:152-154)
+    (tmp_path / "g16.tga").write_bytes(_tga(2, 1, 16, bytes([7, 255, 9, 128]), image_type=3, descriptor=0x20))
+    assert crt.load_image(str(tmp_path / "g16.tga")).tolist() == [[[7, 255], [9, 128]]]
+    # colour-mapped with 16-bit entries, an index beyond the map reads entry 0; run-length packets may cross rows
+    cmap = struct.pack("<HH", 31 << 10, 31 << 5)
+    (tmp_path / "map.tga").write_bytes(_tga(2, 2, 8, bytes([0x82, 1, 0x00, 7]), image_type=9, descriptor=0x20, colour_map=cmap, map_len=2, map_bits=16))
+    assert crt.load_image(str(tmp_path / "map.tga")).tolist() == [[[0, 255, 0], [0, 255, 0]], [[0, 255, 0], [255, 0, 0]]]
+    # a file that ends early reads as zeros from there on
+    (tmp_path / "short.tga").write_bytes(_tga(2, 2, 8, bytes([5, 6]), image_type=3, descriptor=0x20))
+    assert crt.load_image(str(tmp_path / "short.tga"))[:, :, 0].tolist() == [[5, 6], [0, 0]]
+    # not a TGA at all
+    (tmp_path / "junk.tga").write_bytes(bytes(range(40)))
+    with pytest.raises(crt.CrtError, match="no built-in decoder"):
+        crt.load_image(str(tmp_path / "junk.tga"))
+
+
+def test_bmp_texture_in_a_scene(crt, tmp_path):
+    """An image texture in one of the formats a hand-made scene plausibly uses loads through the scene loader."""
+    from PIL import Image
+    img = (np.arange(4 * 4 * 3) * 5 % 256).astype(np.uint8).reshape(4, 4, 3)
+    Image.fromarray(img, "RGB").save(tmp_path / "tex.bmp")
+    Image.fromarray(img, "RGB").save(tmp_path / "tex.tga")
+    for name in ("tex.bmp", "tex.tga"):
+        sc = crt.parse_scene(f"""
+camera: {{type: perspective, from: [0, 0, 5], to: [0, 0, 0], vfov: 40}}
+render: {{width: 8, height: 8, samples: 1, max_bounces: 2}}
+environment: {{texture: {{type: solid_color, color: [0, 0, 0]}}}}
+objects:
+  - {{type: quad, corner: [-1, -1, 0], edge1: [2, 0, 0], edge2: [0, 2, 0], material: {{type: lambertian, texture: {{type: image, filename: {name}}}}}}}
+""", base_dir=str(tmp_path))
+        tex = [t for t in (sc.desc.textures[i] for i in range(sc.desc.texture_count)) if t.type == 2]
+        assert len(tex) == 1 and (tex[0].width, tex[0].height, tex[0].channels) == (4, 4, 4)       # three channels padded to four (texture.cuh:150-151)
+        px = np.ctypeslib.as_array(tex[0].pixels, shape=(4, 4, 4))
+        assert np.array_equal(px[:, :, :3], img) and (px[:, :, 3] == 255).all()
+        sc.close()
