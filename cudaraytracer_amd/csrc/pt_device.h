@@ -342,13 +342,16 @@ __device__ __forceinline__ float reciprocal(float x, int fast) {
 // remainder a - s*q0 comes out of one fma exactly, q = q0 + remainder*r): the correctly rounded
 // quotient whenever r is the correctly rounded reciprocal and nothing underflows (Markstein), five
 // instructions after the shared reciprocal instead of the eleven of the general division sequence;
-// sampled against the IEEE quotient in tools/ubench/rcp_exhaustive.hip.  A zero numerator keeps its
-// sign through q0.  Same condition on the scene as reciprocal().
+// sampled against the IEEE quotient in tools/ubench/rcp_exhaustive.hip.  Same condition on the scene
+// as reciprocal().  The remainder is about 2^-47 |a|: for a numerator below 2^-90 it underflows and the
+// last bit of q can be off (seen up to |a| = 5.2e-28 in that sweep), so numerators below 2^-80, zero
+// among them, take the ordinary division; above that the sweep finds no mismatch.
+constexpr float kSmallNumerator = 0x1p-80f;
 __device__ __forceinline__ float quotient(float a, float s, float r) {
+    if (fabsf(a) < kSmallNumerator) return a / s;
     const float q0 = a * r;
     const float rem = __builtin_fmaf(-s, q0, a);
-    const float q = __builtin_fmaf(rem, r, q0);
-    return a == 0.0f ? q0 : q;
+    return __builtin_fmaf(rem, r, q0);
 }
 template <int FAST>
 __device__ __forceinline__ V3 divide(V3 v, float s) {

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1081,6 +1082,7 @@ static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kMaxDevices = 64;
 constexpr int kWfMaxTraceBlocks = 8192;
 static unsigned char* g_static_scratch[kMaxDevices];     // device address of `scratch` on each GPU
+static std::atomic<int> g_static_busy[kMaxDevices];      // 1 while a crt_render_static call uses that GPU's array
 static std::mutex g_static_scratch_mutex;
 
 // Device address of `scratch` on `device`, which must be the calling thread's current device.
@@ -1530,7 +1532,7 @@ ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacit
     p.pix_padded = p.ntiles * kTileW * p.tile_h;
     const size_t chunk_bytes = (size_t)kPasses * p.pix_padded * sizeof(float);
     const int target_items = sc->opt.work_items > 0 ? sc->opt.work_items : 65536;
-    long long chunks = sc->opt.deterministic ? samples : std::min<long long>(samples, std::max(1, (target_items + p.ntiles - 1) / p.ntiles));
+    long long chunks = sc->opt.deterministic ? samples : std::min<long long>(samples, std::max<long long>(1, ((long long)target_items + p.ntiles - 1) / p.ntiles));
     p.fits = chunk_bytes <= capacity;
     if (!sc->opt.deterministic) chunks = std::max<long long>(1, std::min<long long>(chunks, (long long)(capacity / chunk_bytes)));
     else if ((size_t)chunks * chunk_bytes > capacity) p.fits = false;
@@ -1654,8 +1656,9 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     if (opt.flat_cuboids < 0 || opt.flat_cuboids > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..3");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.exact_ties < 0 || opt.exact_ties > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->exact_ties must be 0 or 1");
+    if (opt.work_items > (1 << 26)) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->work_items must not exceed 67 108 864");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
-        return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range");
+        return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: option out of range (work_items, blocks >= 0; ready_percent 0..100; prim_batch 0..64)");
     int bvh_depth = 0;
     std::string why;
     if (validate(d, bvh_depth, why) != CRT_OK) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: " + why);
@@ -2641,6 +2644,16 @@ int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_
         CRT_HIP(hipSetDevice(sc->device));
         CRT_HIP(static_scratch_address(sc->device, &sc->static_scratch));
     }
+    // Every call on a GPU shares that GPU's array: a second call while one is running (another thread, another
+    // scene) is refused instead of mixing its sums into the first one's.
+    if (sc->device < 0 || sc->device >= kMaxDevices) return crt::set_error(CRT_ERR_UNSUPPORTED, "crt_render_static: device number out of range");
+    struct Busy {
+        std::atomic<int>& flag;
+        bool mine;
+        explicit Busy(std::atomic<int>& f) : flag(f), mine(f.exchange(1) == 0) {}
+        ~Busy() { if (mine) flag.store(0); }
+    } busy(g_static_busy[sc->device]);
+    if (!busy.mine) return crt::set_error(CRT_ERR_INVALID, "crt_render_static: another crt_render_static call is running on this GPU (they share one scratch array)");
     // launch_render() cuts the frame into as many sample chunks as fit the array and refuses an
     // image whose sums of a single chunk (56 bytes per padded pixel) do not
     const ScratchView S = {reinterpret_cast<unsigned long long*>(sc->static_scratch),

@@ -75,6 +75,14 @@ def test_invalid_descriptions_are_refused(crt):
     d = clone(base); d.bvh.object_index = C.cast(oi, type(base.bvh.object_index))
     assert create(crt, d)[0] == -1
 
+    # options out of range (a work item count near INT_MAX would overflow the chunk arithmetic)
+    for field, value in (("work_items", 2**31 - 1), ("work_items", (1 << 26) + 1), ("exact_ties", 2), ("flat_cuboids", 4), ("prim_batch", 65)):
+        other = crt.parse_scene(MINI)
+        other.set_options(**{field: value})
+        with pytest.raises(crt.CrtError) as e:
+            other.upload()
+        assert e.value.status == -1 and field in str(e.value), (field, str(e.value))
+        other.close()
     assert lib.crt_scene_create(None, None) == -1
     assert lib.crt_render(None, None, 1, 0, None, None) == -1
     assert lib.crt_buffers_create(0, 5, C.byref(C.c_void_p())) == -1

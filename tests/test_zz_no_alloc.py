@@ -75,3 +75,78 @@ def test_static_scratch_rejects_images_beyond_its_size(crt):
     assert e.value.status == -5 and "exceed the scratch available" in str(e.value)
     crt.render(sc, buf)                                  # the ordinary entry point is unaffected
     buf.close(); sc.close()
+
+
+def _free_device_bytes():
+    """hipMemGetInfo of the current device, straight from the HIP runtime the library itself uses."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_static_scratch_call_allocates_no_device_memory(crt):
+    """What the entry point is for: between the start and the end of a call the device's free memory does not move
+    (a hipMalloc inside the call, even one that is freed again before it returns, would show in the middle reading)."""
+    import threading
+    sc = crt.load_scene(scene_path("cornell_box.yaml"), base_dir=scene_path(""))
+    sc.set_render(640, 480, samples=16)
+    buf = crt.create_buffer(sc)
+    crt.render_static(sc, buf)                           # warmed up: code object loaded, scratch address known
+    before = _free_device_bytes()
+    lowest = [before]
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            lowest[0] = min(lowest[0], _free_device_bytes())
+
+    t = threading.Thread(target=watch)
+    t.start()
+    try:
+        for _ in range(5):
+            crt.render_static(sc, buf)
+    finally:
+        stop.set()
+        t.join()
+    assert _free_device_bytes() == before and lowest[0] == before, (before, lowest[0], _free_device_bytes())
+    buf.close(); sc.close()
+
+
+def test_overlapping_static_calls_on_one_gpu_are_refused_not_mixed(crt):
+    """Calls on one GPU share one scratch array: a call that arrives while another is running gets an error; every
+    call that does return an image returns the right one."""
+    import threading
+    names = ["cornell_box.yaml", "orthographic.yaml", "cornell_box.yaml", "orthographic.yaml"]
+    scenes, bufs, want = [], [], []
+    for name in names:
+        sc = crt.load_scene(scene_path(name), base_dir=scene_path(""))
+        sc.set_render(160, 120, samples=6)
+        b = crt.create_buffer(sc)
+        crt.render(sc, b)
+        want.append(b.download())
+        scenes.append(sc); bufs.append(b)
+    outcomes = [[] for _ in names]
+    barrier = threading.Barrier(len(names))
+
+    def work(k):
+        for _ in range(6):
+            barrier.wait()
+            try:
+                crt.render_static(scenes[k], bufs[k])
+                got = bufs[k].download()
+                outcomes[k].append(all(np.array_equal(got[p].view(np.uint32), want[k][p].view(np.uint32)) for p in oracle_lib.PASSES))
+            except crt.CrtError as e:
+                outcomes[k].append("another crt_render_static call is running" in str(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(names))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(all(o) and len(o) == 6 for o in outcomes), outcomes
+    for b in bufs:
+        b.close()
+    for sc in scenes:
+        sc.close()
