@@ -1,6 +1,6 @@
 """The host-side pins (BVH4 builder, scene loader, oracle against the published images, image
 decoders and writers, the plain-float acos/atan2/sin/cos, the exported C ABI, the 2-rank CPU
-rehearsal of the multi-GPU splits, bench.py's launcher) once more under the `gpu` marker: they need
+rehearsal of the multi-GPU splits, bench.py's launcher, the float32 check of the far-face safe distance) once more under the `gpu` marker: they need
 no GPU, but the GPU-marked run is the one that is repeated on the MI355X machine, and a parity claim
 made there rests on these as much as on the device tests."""
 import pytest
@@ -16,5 +16,6 @@ from test_det_math import *             # noqa: F401,F403
 from test_capi_symbols import *         # noqa: F401,F403
 from test_multi_gpu_cpu import *        # noqa: F401,F403
 from test_bench_launcher import *       # noqa: F401,F403
+from test_far_faces import *            # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu
