@@ -274,14 +274,16 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=50, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-configs", action="store_true", help="N = 1, headline scene: skip the other BASELINE configurations")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks as child processes even for one GPU (rehearses the parent / child path and the collectives on a one-GPU machine)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
 
     launched = "RANK" in os.environ
-    if not launched and args.gpus > 1:
+    if not launched and (args.gpus > 1 or args.launch):
         # the parent of an N-rank run: it never touches a GPU itself
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--launch"]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -343,9 +345,8 @@ def main():
             if args.sharding != "auto":
                 multi_gpu.check_sharding(args.sharding, H, spp, world)
                 sharding = args.sharding
-            elif world == 1:
-                sharding = "samples"
             else:
+                # (also with a single rank under a launcher: a one-GPU machine then rehearses every step of the N-rank run)
                 multi_gpu.choose_sharding(W, H, spp, world)      # raises if neither split is possible
                 # the cost model wants this scene's frame time on one GPU: render the whole frame once
                 # on every rank (after one untimed frame) and take the slowest
