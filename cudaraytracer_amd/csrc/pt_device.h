@@ -125,7 +125,10 @@ enum : int {
     kFeatAll = 0x1ff,
     kFeatExactTies = 1 << 9,    // tree walks only, on request: near-ties decided the way the reference's ordered walk decides them (consider_exact())
     kFeatBasic = 0,             // untransformed flat triangles under diffuse materials and lights of one colour, pinhole camera
-    kFeatBasicXform = kFeatXform   // the same with transformed objects (rotated boxes)
+    kFeatBasicXform = kFeatXform,  // the same with transformed objects (rotated boxes)
+    // any shapes, transforms and camera kinds under diffuse materials and lights of one colour, environment of one colour
+    // (no textures or normal maps, no metal or glass: none of the code that looks things up per hit)
+    kFeatPlain = kFeatPlainXf | kFeatSphere | kFeatSlotXf | kFeatCamera | kFeatXform
 };
 
 struct DevImage {

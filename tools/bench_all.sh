@@ -3,7 +3,7 @@
 # command (run on the GPU box from the repo root):  tools/bench_all.sh <tag>
 # Results: gpurun_out/<tag>_bench_<scene>.json, gpurun_out/<tag>_stats_<scene>.csv
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 run() {   # scene steps warmup extra...
@@ -16,7 +16,7 @@ run() {   # scene steps warmup extra...
   rm -rf $OUT/${TAG}_prof_$N
   cat $OUT/${TAG}_bench_$N.json
 }
-run cornell_box.yaml 20 3 &&
+run cornell_box.yaml 20 3 --no-configs &&
 run orthographic.yaml 20 3 --cpu-spp 0 &&
 run obj.yaml 20 3 --cpu-spp 0 &&
 run materials.yaml 20 3 --cpu-spp 0 &&

@@ -2,7 +2,7 @@
 # The N > 1 code paths of bench.py with ONE rank under torch.distributed.run (RCCL loaded, the
 # collectives and the assemble kernel run): tools/rehearse_dist.sh <tag>
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 for MODE in "--sharding tiles" "--sharding samples" "--scaling weak"; do
   N=$(echo $MODE | tr -d ' -')

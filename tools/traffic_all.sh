@@ -3,7 +3,7 @@
 # rocprofv3 --pmc runs (one launch of the scene's frame each), summed over the kernel's dispatches.
 #   tools/traffic_all.sh <tag>   ->  gpurun_out/<tag>_traffic.json   (run on the GPU box from the repo root)
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for S in cornell_box orthographic obj materials materials_hdr mesh1m; do
