@@ -1408,61 +1408,65 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
     return out;
 }
 
+// Material record, two quads.  First: {kind, texture, fuzz, ior}; a lambertian material or light whose texture is
+// one colour carries that colour instead: {kind | kMatOneColour, r, g, b} (no second lookup for what most hits need).
+// Second: metal {albedo r, g, b, -}; dielectric {1 / ior, r0 of a front-face hit, r0 of a back-face hit, -}, the
+// Schlick constants ((1 - ratio) / (1 + ratio))^2 of material.cuh:183-187 for ratio = 1 / ior and ratio = ior,
+// evaluated on the host with the same float operations.
+constexpr int kMatOneColour = 16;
+__device__ __forceinline__ int material_kind(float4 m0) { return __float_as_int(m0.x) & 15; }
+
 // material::scatter (material.cuh:359-372) with the sphere sample already drawn (see
 // coop_sphere_sample): `rv` is the random unit vector for a lambertian surface, the in-sphere
 // vector for a metal.  Returns false when the material does not scatter (light, or a metal
 // bounce that points into the surface).
 template <int FEAT = kFeatAll, int FAST = 0>
 __device__ __forceinline__ bool scatter_with(const DevScene& sc, const Ray& in, const Surface& s, float4 m0, V3 rv, Rng& rng, V3& attenuation, Ray& out) {
-    int type = __float_as_int(m0.x);
+    const int type = material_kind(m0);
     out.time = in.time;
     if (type == 0) {                                           // lambertian :290-297
         V3 dir = s.normal + rv;
         if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = s.normal;
         out.o = s.p + s.normal * 0.001f;
         out.d = dir;
-        attenuation = texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
+        if (!(FEAT & kFeatShading) || (__float_as_int(m0.x) & kMatOneColour)) attenuation = v3(m0.y, m0.z, m0.w);
+        else attenuation = texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
         return true;
     }
     if (!(FEAT & kFeatMaterials)) return false;                // neither metal nor glass in the scene: a light
+    if (type != 1 && type != 2) return false;
+    // metal and glass both start from the unit direction and the cosine at the surface
+    const float4 m1 = *at32(sc.mats, s.mat * 2 + 1);
+    const V3 unit_dir = unit_vector<FAST>(in.d);
+    const float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
+    out.o = s.p;
     if (type == 1) {                                           // metal :311-322
-        float4 m1 = *at32(sc.mats, s.mat * 2 + 1);
-        V3 unit_dir = unit_vector<FAST>(in.d);
         V3 reflected = reflect(unit_dir, s.normal);
-        out.o = s.p;
         out.d = reflected + m0.z * rv;
-        float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
         V3 albedo = v3(m1.x, m1.y, m1.z);
         attenuation = albedo + (v3(1.0f, 1.0f, 1.0f) - albedo) * pow5(1.0f - cos_theta);
         return dot(out.d, s.normal) > 0.0f;
     }
-    if (type == 2) {                                           // dielectric :336-356
-        attenuation = v3(1.0f, 1.0f, 1.0f);
-        float ior = m0.w;
-        float ratio = s.front ? (1.0f / ior) : ior;
-        V3 unit_dir = unit_vector<FAST>(in.d);
-        float cos_theta = fminf(dot(-unit_dir, s.normal), 1.0f);
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        bool do_reflect = ratio * sin_theta > 1.0f;
-        if (!do_reflect) {                                     // the uniform is drawn only when refraction is possible
-            float r0 = (1.0f - ratio) / (1.0f + ratio);
-            r0 = r0 * r0;
-            float reflectance = r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
-            do_reflect = reflectance > rng.uniform();
-        }
-        out.o = s.p;
-        out.d = do_reflect ? reflect(unit_dir, s.normal) : refract(unit_dir, s.normal, ratio);
-        return true;
+    // dielectric :336-356
+    attenuation = v3(1.0f, 1.0f, 1.0f);
+    const float ratio = s.front ? m1.x : m0.w;                 // 1 / ior : ior
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    bool do_reflect = ratio * sin_theta > 1.0f;
+    if (!do_reflect) {                                         // the uniform is drawn only when refraction is possible
+        const float r0 = s.front ? m1.y : m1.z;
+        float reflectance = r0 + (1.0f - r0) * pow5(1.0f - cos_theta);
+        do_reflect = reflectance > rng.uniform();
     }
-    return false;
+    out.d = do_reflect ? reflect(unit_dir, s.normal) : refract(unit_dir, s.normal, ratio);
+    return true;
 }
 
-// material::emit (material.cuh:375-381)
+// material::emit (material.cuh:375-381); m0 = the first quad of the hit's material record
 template <int FEAT = kFeatAll>
-__device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s) {
-    float4 m0 = *at32(sc.mats, s.mat * 2);
-    if (__float_as_int(m0.x) == 3) return texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
-    return v3(0.0f, 0.0f, 0.0f);
+__device__ __forceinline__ V3 emit(const DevScene& sc, const Surface& s, float4 m0) {
+    if (material_kind(m0) != 3) return v3(0.0f, 0.0f, 0.0f);
+    if (!(FEAT & kFeatShading) || (__float_as_int(m0.x) & kMatOneColour)) return v3(m0.y, m0.z, m0.w);
+    return texture_value<FEAT>(sc, __float_as_int(m0.y), s.u, s.v, s.p);
 }
 // Environment lookup on a miss (render.cuh:77-82)
 template <int FEAT = kFeatAll, int FAST = 0>

@@ -313,17 +313,25 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     // instruction.  (LDS executes a wave's instructions in order; the fences only keep the compiler from moving
     // or caching the accesses.)
     constexpr bool kAtomicSums = MODE == kModeFlat && FEAT == kFeatBasicXform;
+    SectionClock clk;
+    // (profiling build, flat mode: the time in the additions to the tile sums is booked under the tree walk's section, which the flat mode does not use)
     auto accumulate = [&](auto&& adds) {
-        if constexpr (kAtomicSums) { adds(); return; }
-        bool todo = true;
-        while (true) {
-            if (todo) tag[pixoff] = lane;
-            wave_lds_sync();
-            const bool win = todo && tag[pixoff] == lane;
-            if (win) { adds(); todo = false; }
-            wave_lds_sync();
-            if (!lanes_where(todo)) break;
+        [[maybe_unused]] float dep = 0.0f;
+        if constexpr (MODE == kModeFlat) CRT_CLOCK(clk, kSecNode, dep);
+        if constexpr (kAtomicSums) {
+            adds();
+        } else {
+            bool todo = true;
+            while (true) {
+                if (todo) tag[pixoff] = lane;
+                wave_lds_sync();
+                const bool win = todo && tag[pixoff] == lane;
+                if (win) { adds(); todo = false; }
+                wave_lds_sync();
+                if (!lanes_where(todo)) break;
+            }
         }
+        if constexpr (MODE == kModeFlat) CRT_CLOCK(clk, kSecScatter, dep);
     };
 
     // Flat mode: the lanes at their first hit are exactly the ones that took a new path at the top of this
@@ -331,11 +339,16 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     // worth of paths started at once.  Then they add without asking.
     bool first_hits_unique = false;
     auto accumulate_first = [&](auto&& adds) {
-        if (kAtomicSums || (MODE == kModeFlat && first_hits_unique)) adds();
-        else accumulate(adds);
+        if (kAtomicSums || (MODE == kModeFlat && first_hits_unique)) {
+            [[maybe_unused]] float dep = 0.0f;
+            if constexpr (MODE == kModeFlat) CRT_CLOCK(clk, kSecNode, dep);
+            adds();
+            if constexpr (MODE == kModeFlat) CRT_CLOCK(clk, kSecScatter, dep);
+        } else {
+            accumulate(adds);
+        }
     };
 
-    SectionClock clk;
     clk.start();
     while (true) {
         CRT_PROF(kProfOuter);
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                 if constexpr (MODE == kModeFlat) h.obj = *at32(A.flat.ent_obj, h.obj);
                 sf = make_surface<false, FEAT, FAST>(sc, ray, h);
                 m0 = *at32(sc.mats, sf.mat * 2);
-                mat_type = __float_as_int(m0.x);
+                mat_type = material_kind(m0);
             }
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
@@ -443,12 +456,17 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             if (h.obj >= 0) {
                 V3 attenuation;
                 Ray next;
+                // what the normal and depth passes show of a first hit, whichever way the path goes on (render.cuh:55-56, 69-70)
+                V3 n = v3(0.0f, 0.0f, 0.0f);
+                float depth = 0.0f;
+                if (bounces == 0) {
+                    n = sf.unit_normal;
+                    if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
+                    depth = h.t * length(ray.d);
+                }
                 if (scatter_with<FEAT, FAST>(sc, ray, sf, m0, rv_dep, rng, attenuation, next)) {  // render.cuh:52-61
                     if (bounces == 0) {
                         set_pending_albedo(attenuation);
-                        V3 n = sf.unit_normal;
-                        if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
-                        const float depth = h.t * length(ray.d);
                         accumulate_first([&]() {
                             acc_add3<kTilePixels, kAtomicSums>(acc, 9, pixoff, n);
                             acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, depth);
@@ -461,17 +479,10 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     if (bounces >= sc.max_bounces) alive = false;   // exhausted: col = albedo = 0 (render.cuh:96-97)
                     else if constexpr (MODE != kModeFlat) { ts.begin(INFINITY, sc.root_entry); walking = true; }
                 } else {                                             // render.cuh:64-74
-                    V3 emitted = emit<FEAT>(sc, sf);
+                    V3 emitted = emit<FEAT>(sc, sf, m0);
                     V3 c = throughput * emitted;
                     V3 alb = emitted;
                     if (bounces != 0) alb = pending_albedo();
-                    V3 n = v3(0.0f, 0.0f, 0.0f);
-                    float depth = 0.0f;
-                    if (bounces == 0) {
-                        n = sf.unit_normal;
-                        if (!sf.has_unit) n = unit_vector<FAST>(sf.normal);
-                        depth = h.t * length(ray.d);
-                    }
                     accumulate([&]() {
                         acc_add3<kTilePixels, kAtomicSums>(acc, 0, pixoff, c);
                         if (bounces == 0) {
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
         if (active && h.obj >= 0) {
             sf = make_surface<false>(sc, ray, h);
             m0 = *at32(sc.mats, sf.mat * 2);
-            mat_type = __float_as_int(m0.x);
+            mat_type = material_kind(m0);
         }
         const V3 rv = coop_sphere_sample(mat_type == 0 || mat_type == 1, mat_type == 1, rng, coop_pub, coop_res, lane);
         bool alive = false;                                   // the path goes on to the next bounce
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
                     ray = next;
                     alive = bounces + 1 < (unsigned int)sc.max_bounces;     // exhausted: col = albedo = 0 (render.cuh:96-97)
                 } else {                                                                      // render.cuh:64-74
-                    const V3 emitted = emit(sc, sf);
+                    const V3 emitted = emit(sc, sf, m0);
                     color = throughput * emitted;
                     albedo = pend_albedo;
                     if (bounces == 0) {
@@ -1823,6 +1834,17 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
         float* r = &mat_rec[(size_t)i * 8];
         r[0] = as_float(m.type); r[1] = as_float(m.tex_idx); r[2] = m.fuzz; r[3] = m.ior;
         r[4] = m.albedo[0]; r[5] = m.albedo[1]; r[6] = m.albedo[2];
+        // (layout and the two shortcuts: "Material record" in pt_device.h)
+        if ((m.type == CRT_MAT_LAMBERTIAN || m.type == CRT_MAT_DIFFUSE_LIGHT) && m.tex_idx >= 0 && m.tex_idx < d->texture_count &&
+            d->textures[m.tex_idx].type == CRT_TEX_SOLID_COLOR) {
+            const crt_texture& t = d->textures[m.tex_idx];
+            r[0] = as_float(m.type | kMatOneColour); r[1] = t.color[0]; r[2] = t.color[1]; r[3] = t.color[2];
+        }
+        if (m.type == CRT_MAT_DIELECTRIC) {
+            auto schlick_r0 = [](float ratio) { float r0 = (1.0f - ratio) / (1.0f + ratio); return r0 * r0; };
+            const float inv_ior = 1.0f / m.ior;
+            r[4] = inv_ior; r[5] = schlick_r0(inv_ior); r[6] = schlick_r0(m.ior);
+        }
     }
     std::vector<float> tex_rec((size_t)d->texture_count * 8, 0.0f);
     std::vector<DevImage> images;

@@ -11,7 +11,7 @@ run() {   # scene steps warmup extra...
   local N=${S%.yaml}
   timeout -k 10 400 python3 $GRAFT_REPO_ROOT/bench.py --scene $S --steps $K --warmup $Wm "$@" > $OUT/${TAG}_bench_$N.json 2> $OUT/${TAG}_bench_$N.err || { echo "bench $S failed"; tail -5 $OUT/${TAG}_bench_$N.err; return 1; }
   rm -rf $OUT/${TAG}_prof_$N
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_$N -- python3 $GRAFT_REPO_ROOT/bench.py --scene $S --steps $K --warmup $Wm --cpu-spp 0 > $OUT/${TAG}_prof_$N.json 2> $OUT/${TAG}_prof_$N.err || { echo "rocprof $S failed"; tail -5 $OUT/${TAG}_prof_$N.err; return 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_$N -- python3 $GRAFT_REPO_ROOT/bench.py --scene $S --steps $K --warmup $Wm "$@" --cpu-spp 0 > $OUT/${TAG}_prof_$N.json 2> $OUT/${TAG}_prof_$N.err || { echo "rocprof $S failed"; tail -5 $OUT/${TAG}_prof_$N.err; return 1; }
   find $OUT/${TAG}_prof_$N -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_stats_$N.csv \;
   rm -rf $OUT/${TAG}_prof_$N
   cat $OUT/${TAG}_bench_$N.json

@@ -31,7 +31,7 @@ if int(out[16:32].sum()):
     print("flat mode, fullest lane of the wave  :", " ".join(f"{k}:{v / waves.sum() * 100:5.1f}%" for k, v in enumerate(waves)),
           f" mean {sum(k * v for k, v in enumerate(waves)) / waves.sum():.3f}")
     print("candidate bits of rays with >= 3     :", " ".join(f"{b}:{int(v)}" for b, v in enumerate(out[64:128]) if v))
-secs_names = ["other", "regen", "box", "prim", "surface", "sample", "scatter", "node"]
+secs_names = ["other", "regen", "box", "prim", "surface", "sample", "scatter", "node (flat mode: additions to the tile sums)"]
 tot = float(sum(int(out[32 + k]) for k in range(8)))
 if tot:
     print("wave clock share per section:")
