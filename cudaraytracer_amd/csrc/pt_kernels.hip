@@ -163,7 +163,7 @@ constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
 constexpr int kItemWords = 8;                    // per wave: the cold part of its work items (tile position, first sample, ...)
 constexpr int kTagWords = 64;                    // per wave: which lane adds to a pixel of the two open items this round
-constexpr int kParkWords = 3;                    // flat mode: per-lane path state kept in LDS
+constexpr int kParkWords = 4;                    // flat mode: per-lane path state kept in LDS (albedo to show, place in the tile sums)
 static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
 constexpr int wave_lds_bytes(int mode) { return (acc_floats_per_wave(mode) + kCoopWordsPerWave + kItemWords + kTagWords) * 4 + kCamWords * 4 / kWaves; }
 
@@ -197,9 +197,12 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     // have the registers (cap 128) and are faster with them.
     constexpr bool kItemInLds = MODE == kModeFlat;
     typedef volatile int __attribute__((address_space(3))) * LdsVolatileIntPtr;
-    LdsVolatileIntPtr item_mem = (LdsVolatileIntPtr)(reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords) + (threadIdx.x >> 6) * kItemWords);
+    // (the wave's number, said to be the same in every lane: what is derived from it - the wave's parts of the LDS - then sits in
+    // scalar registers instead of vector registers that are live, or spilled to scratch memory, through the whole kernel)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    LdsVolatileIntPtr item_mem = (LdsVolatileIntPtr)(reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords) + wave * kItemWords);
     static_assert(2 * kTilePixels <= kTagWords, "one tag word per pixel of the two open items");
-    int* tag = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * kItemWords) + (threadIdx.x >> 6) * kTagWords;
+    int* tag = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * kItemWords) + wave * kTagWords;
     int* stack_mem = reinterpret_cast<int*>(coop_all + kWaves * kCoopWordsPerWave + kCamWords + kWaves * (kItemWords + kTagWords));
     float* entry_mem = reinterpret_cast<float*>(stack_mem + STACK * kBlock);      // tree modes: 4 slot codes + 4 box entry distances per lane
     // Flat mode: the albedo a path shows in the albedo pass is found at its first hit and only added when
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     const DevScene& sc = A.sc;
     if (threadIdx.x == 0) *lds_cam = sc.cam;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     float* acc = acc_all + wave * kAccFloatsPerWave;              // [2][14][tile pixels] sums of the wave's two open tiles
     uint32_t* coop_pub = coop_all + wave * kCoopWordsPerWave;
     // (every lane has read the published streams before any lane stores a candidate point: one wave, LDS in order)
@@ -288,7 +291,19 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
 
     unsigned int rays = 0;
     bool alive = false;
-    int pixoff = 0;                                               // item buffer * tile pixels + pixel of the tile: where this lane's path adds its results
+    // item buffer * tile pixels + pixel of the tile: where this lane's path adds its results.  Set where a path starts and read where
+    // it adds; the flat variants that are short of registers keep it in LDS beside the pending albedo (the compiler
+    // otherwise spills it to scratch memory: a store per path and a load per addition).
+    constexpr bool kPixoffInLds = MODE == kModeFlat && FEAT != kFeatBasicXform;
+    int pixoff_reg = 0;
+    auto set_pixoff = [&](int v) {
+        if constexpr (kPixoffInLds) reinterpret_cast<int*>(park_of_lane())[3 * kBlock] = v;
+        else pixoff_reg = v;
+    };
+    auto get_pixoff = [&]() {
+        if constexpr (kPixoffInLds) return reinterpret_cast<const int*>(park_of_lane())[3 * kBlock];
+        else return pixoff_reg;
+    };
     Ray ray;
     ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
     V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);       // (pend_albedo: tree modes; flat mode keeps it in `park`)
@@ -322,6 +337,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             adds();
         } else {
             bool todo = true;
+            const int pixoff = get_pixoff();
             while (true) {
                 if (todo) tag[pixoff] = lane;
                 wave_lds_sync();
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         }
         // the drained item is complete when none of its paths is alive any more
         if (draining) {
-            const bool mine = alive && ((pixoff >= kTilePixels) == ((fill_buffer ^ 1) != 0));
+            const bool mine = alive && ((get_pixoff() >= kTilePixels) == ((fill_buffer ^ 1) != 0));
             if (!lanes_where(mine)) {
                 if constexpr (kItemInLds) flush(fill_buffer ^ 1, item_mem[6], item_mem[7]);
                 else flush(fill_buffer ^ 1, drain_tile, drain_chunk);
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     const int sample = s0 + item / kTilePixels + 1;       // sample numbers are 1-based (render.cuh:128)
                     const int pi = tx * kTileW + (pix & 7), pj = ty * kTileH + (pix >> 3);
                     if (pi < sc.width && pj < sc.height && sc.max_bounces > 0) {
-                        pixoff = fill_buffer * kTilePixels + pix;
+                        set_pixoff(fill_buffer * kTilePixels + pix);
                         rng.init(pj * sc.width + pi, sample);
                         ray = camera_ray<FEAT>(*lds_cam, pi, pj, rng);
                         throughput = v3(1, 1, 1);
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     if (bounces == 0) {
                         set_pending_albedo(attenuation);
                         accumulate_first([&]() {
+                            const int pixoff = get_pixoff();
                             acc_add3<kTilePixels, kAtomicSums>(acc, 9, pixoff, n);
                             acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, depth);
                             acc_add<kTilePixels, kAtomicSums>(acc, 13, pixoff, 1.0f);
@@ -484,6 +501,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                     V3 alb = emitted;
                     if (bounces != 0) alb = pending_albedo();
                     accumulate([&]() {
+                        const int pixoff = get_pixoff();
                         acc_add3<kTilePixels, kAtomicSums>(acc, 0, pixoff, c);
                         if (bounces == 0) {
                             acc_add3<kTilePixels, kAtomicSums>(acc, 6, pixoff, emitted);
@@ -500,6 +518,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
                 V3 alb = c;
                 if (bounces != 0) alb = pending_albedo();
                 accumulate([&]() {
+                    const int pixoff = get_pixoff();
                     acc_add3<kTilePixels, kAtomicSums>(acc, 0, pixoff, c);
                     if (bounces == 0) acc_add<kTilePixels, kAtomicSums>(acc, 12, pixoff, __builtin_nanf(""));   // depth of a miss is NaN (render.cuh:88)
                     acc_add3<kTilePixels, kAtomicSums>(acc, 3, pixoff, alb);
