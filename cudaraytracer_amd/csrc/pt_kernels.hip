@@ -78,6 +78,12 @@ enum : int {
     kModeFlat = 2          // <= 64 box slots: wave-uniform box loop + per-lane candidate mask
 };
 
+// Work-item counters of a launch: the ray count in the first words, then kQueues counters kQueueStride words apart
+// (each in a memory channel of its own).
+constexpr int kQueues = 8;
+constexpr int kQueueStride = 64;
+constexpr size_t kCounterBytes = (size_t)(kQueues + 1) * kQueueStride * sizeof(unsigned int);
+
 struct RenderArgs {
     DevScene sc;
     FlatView flat;                   // small-scene box slots (flat mode)
@@ -86,6 +92,7 @@ struct RenderArgs {
     int* stack_spill;                // tree modes: global part of the traversal stacks, [entries][spill_threads]
     int spill_threads;
     unsigned int* queue;             // next work item (tile, chunk) to hand out; zero at launch
+    // (kQueues counters, kQueueStride words apart, each handing out the items i with i % kQueues == its number)
     int tiles_x, tiles_y, ntiles, pix_padded;
     int first_sample, samples, chunk_size, chunks;
     int prim_batch;                  // tree modes: lanes with leaf candidates that trigger a round of primitive tests
@@ -161,7 +168,7 @@ __device__ __forceinline__ void acc_add3(float* acc, int plane, int slot, V3 v) 
 constexpr int kCoopWordsPerWave = 192;          // coop_sphere_sample: published streams (128 words), then candidate points (192) over them
 constexpr int acc_floats_per_wave(int mode) { return 2 * kPasses * kTileW * tile_rows(mode); }   // two work items in flight per wave
 constexpr int kCamWords = 32;                    // DevCamera copy of the block
-constexpr int kItemWords = 8;                    // per wave: the cold part of its work items (tile position, first sample, ...)
+constexpr int kItemWords = 16;                   // per wave: the cold part of its work items (tile position, first sample, ...)
 constexpr int kTagWords = 64;                    // per wave: which lane adds to a pixel of the two open items this round
 constexpr int kParkWords = 4;                    // flat mode: per-lane path state kept in LDS (albedo to show, place in the tile sums)
 static_assert(sizeof(DevCamera) <= kCamWords * 4, "camera copy does not fit");
@@ -244,11 +251,32 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
 
     const int item_count = A.ntiles * A.chunks;
     // next work item of this wave (wave-uniform); invalid once the counter has run past the end
+    // The work items come from kQueues counters, counter k handing out the items i with i % kQueues == k: additions to
+    // ONE address from the whole chip go through one after the other, about 85 million a second, and a frame of
+    // many short items (a small scene in front of a black background) asks for more than that.  A wave starts at
+    // the counter of its block's number (blocks go round the chip's eight dies) and, once a counter has run out,
+    // goes on with the next one for good; when all have run out the queue is empty.
+    // (which counter, and how many have run out: flat mode keeps the two in LDS with the rest of the item)
+    unsigned int queue_at = blockIdx.x % kQueues, queues_out = 0;
+    if constexpr (kItemInLds) { if (lane == 0) { item_mem[8] = (int)queue_at; item_mem[9] = 0; } }
     auto fetch = [&]() {
         WorkItem w = {};
-        unsigned int q = 0;
-        if (lane == 0) q = atomicAdd(A.queue, 1u);
-        q = __builtin_amdgcn_readfirstlane(q);
+        unsigned int at = kItemInLds ? (unsigned int)item_mem[8] : queue_at;
+        unsigned int out = kItemInLds ? (unsigned int)item_mem[9] : queues_out;
+        at = __builtin_amdgcn_readfirstlane(at);
+        out = __builtin_amdgcn_readfirstlane(out);
+        unsigned int q = 0xffffffffu;
+        while (out < (unsigned int)kQueues) {
+            unsigned int n = 0;
+            if (lane == 0) n = atomicAdd(A.queue + at * kQueueStride, 1u);
+            n = __builtin_amdgcn_readfirstlane(n);
+            // (n never comes near 2^32 / kQueues: a counter stops rising once every wave has seen it run out)
+            if (n * kQueues + at < (unsigned int)item_count) { q = n * kQueues + at; break; }
+            out++;
+            at = (at + 1) % kQueues;
+        }
+        if constexpr (kItemInLds) { if (lane == 0) { item_mem[8] = (int)at; item_mem[9] = (int)out; } }
+        else { queue_at = at; queues_out = out; }
         w.valid = q < (unsigned int)item_count;
         const int chunk = (int)(q / (unsigned int)A.ntiles);
         const int tile = (int)q - chunk * A.ntiles;
@@ -1102,10 +1130,10 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(ProbeArgs A) {
 using namespace crt;
 
 // Scratch of crt_render_static(), the entry point for callers that must not allocate: counters
-// (first 256 bytes) and chunk sums.  One copy per GPU, held until the process ends.  In host code
+// (the first kCounterBytes) and chunk sums.  One copy per GPU, held until the process ends.  In host code
 // the array's name is only a handle for hipGetSymbolAddress(); the device address it yields (one
 // per device, taken with that device current) is what every launch and memset uses.
-constexpr size_t kStaticCounterBytes = 256;
+constexpr size_t kStaticCounterBytes = kCounterBytes;
 constexpr size_t kStaticScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
@@ -1534,7 +1562,7 @@ bool primitives_inside_their_boxes(const crt_scene_desc* d) {
 }
 
 // How a launch of `samples` samples is cut into work items: every pixel tile x a chunk of the
-// samples.  About 16 items per resident wave keep the end of the launch (waves running dry one by
+// samples.  About 16 to 24 items per resident wave keep the end of the launch (waves running dry one by
 // one) to a few percent of its length.  `capacity` = bytes of chunk-sum scratch available.
 struct ChunkPlan {
     int tile_h, tiles_x, tiles_y, ntiles, pix_padded, chunk_size, chunks;
@@ -1563,12 +1591,21 @@ ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacit
     p.ntiles = p.tiles_x * p.tiles_y;
     p.pix_padded = p.ntiles * kTileW * p.tile_h;
     const size_t chunk_bytes = (size_t)kPasses * p.pix_padded * sizeof(float);
-    const int target_items = sc->opt.work_items > 0 ? sc->opt.work_items : 65536;
+    // (98304: the best compromise of a sweep over 32768 ... 262144 on the scenes of this repository; scenes with long
+    // paths of very different lengths - glass spheres, 30 bounces - still gain 3 % at 131072, scenes with short paths lose 3 %)
+    const int target_items = sc->opt.work_items > 0 ? sc->opt.work_items : 98304;
     long long chunks = sc->opt.deterministic ? samples : std::min<long long>(samples, std::max<long long>(1, ((long long)target_items + p.ntiles - 1) / p.ntiles));
     p.fits = chunk_bytes <= capacity;
     if (!sc->opt.deterministic) chunks = std::max<long long>(1, std::min<long long>(chunks, (long long)(capacity / chunk_bytes)));
     else if ((size_t)chunks * chunk_bytes > capacity) p.fits = false;
     p.chunk_size = (int)((samples + chunks - 1) / chunks);
+    // An even number of samples, so that an item's paths fill whole waves (a tile has 32 pixels).  Where paths are short
+    // and alike - a sphere in front of an environment map: two rays each - the lanes of a wave stay in step, all at
+    // their first hit in one round and all leaving the scene in the next, and each round runs one branch of the
+    // shading code.  Half a wave of paths left over at the end of an item splits the wave into two groups a round
+    // apart for the rest of the launch, and every round runs both branches: measured 20 % slower (that scene at 297
+    // against 300 samples in three chunks), 10 % with an environment map alone, 6 % on the orthographic cube.
+    if (!sc->opt.deterministic && p.chunk_size > 1) p.chunk_size += p.chunk_size & 1;
     p.chunks = (samples + p.chunk_size - 1) / p.chunk_size;
     p.bytes = (size_t)p.chunks * chunk_bytes;
     return p;
@@ -2242,7 +2279,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
-    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, 2 * sizeof(unsigned long long)));
+    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, kCounterBytes));
     sc->spill_entries = std::max(0, need - (stack_entries - 1));       // one LDS row is the row of -1 below the stacks
     sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), std::max(CRT_TREE_WAVES_PER_SIMD, CRT_TREE_BASIC_WAVES_PER_SIMD)), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
@@ -2469,7 +2506,7 @@ int crt_buffers_upload(crt_buffers* b, const float* color, const float* albedo, 
 
 // Where a launch keeps its chunk sums and counters.
 struct ScratchView {
-    unsigned long long* counters;    // [0] rays traced, [1] next work item
+    unsigned long long* counters;    // kCounterBytes: rays traced, then the work-item counters
     float* partial;
     size_t partial_bytes;
 };
@@ -2519,8 +2556,8 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     A.band_index = bands.index;
     A.band_count = bands.count;
     A.ray_counter = S.counters;
-    A.queue = reinterpret_cast<unsigned int*>(S.counters + 1);
-    CRT_HIP(hipMemsetAsync(S.counters, 0, 2 * sizeof(unsigned long long), sc->stream));
+    A.queue = reinterpret_cast<unsigned int*>(S.counters) + kQueueStride;
+    CRT_HIP(hipMemsetAsync(S.counters, 0, kCounterBytes, sc->stream));
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
     const long long items = (long long)plan.ntiles * plan.chunks;
     int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc), variant_features(sc)) / kWaves);   // 4 SIMDs per CU

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cudaraytracer_amd as crt
 from cudaraytracer_amd import api
+import ctypes as C
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -29,6 +30,8 @@ for r in range(reps):
     wall = time.time() - t0
     rays = api.last_ray_count
     times.append(secs)
-    print(f"{name} rep{r}: device {secs*1e3:.2f} ms wall {wall*1e3:.2f} ms rays {rays} -> {rays/secs/1e6:.1f} Mrays/s", flush=True)
+    tr, rs = C.c_float(0), C.c_float(0)
+    crt.lib().crt_render_timings(sc.get_device_scene(), C.byref(tr), C.byref(rs))
+    print(f"{name} rep{r}: device {secs*1e3:.2f} ms (path kernel {tr.value:.3f}, resolve {rs.value:.3f}) wall {wall*1e3:.2f} ms rays {rays} -> {rays/secs/1e6:.1f} Mrays/s", flush=True)
 warm = sorted(times[1:] or times)
 print(f"{name} summary: median {warm[len(warm) // 2]*1e3:.3f} ms  min {warm[0]*1e3:.3f} ms  over {len(warm)} warm frames  ({sc.describe()})", flush=True)
