@@ -61,9 +61,10 @@ __device__ __forceinline__ void prof_tick(int site) {
 #endif
 #ifdef CRT_PROFILE_CLOCK
 struct SectionClock {
-    unsigned long long last, acc[8];
+    unsigned long long last, acc[8], began;
     int cur;
     __device__ __forceinline__ void start() {
+        began = wall_clock64();        // (100 MHz, one counter for the whole chip)
         for (int k = 0; k < 8; k++) acc[k] = 0;
         cur = 0;
         float dep = 0.0f;
@@ -84,8 +85,16 @@ struct SectionClock {
     __device__ __forceinline__ void flush() {
         float dep = 0.0f;
         mark(0, dep);
-        if ((threadIdx.x & 63) == 0)
+        if ((threadIdx.x & 63) == 0) {
             for (int k = 0; k < 8; k++) atomicAdd(&g_prof[32 + k], acc[k]);
+            // when the waves began and ended: earliest start (kept as the largest complement), latest end, sum of ends, waves
+            const unsigned long long ended = wall_clock64();
+            atomicMax(&g_prof[40], ~began);
+            atomicMax(&g_prof[41], ended);
+            atomicAdd(&g_prof[42], ended - began);
+            atomicAdd(&g_prof[43], 1ull);
+            atomicMax(&g_prof[44], began);
+        }
     }
 };
 #define CRT_CLOCK(clk, section, dep) (clk).mark(section, dep)

@@ -82,7 +82,29 @@ enum : int {
 // (each in a memory channel of its own).
 constexpr int kQueues = 8;
 constexpr int kQueueStride = 64;
-constexpr size_t kCounterBytes = (size_t)(kQueues + 1) * kQueueStride * sizeof(unsigned int);
+// Behind them: how many items fell into each class of measured cost, and how many of each class have been placed in
+// the order of the next launch (order_by_cost).
+constexpr int kCostClasses = 128;
+constexpr int kCostWordsAt = (kQueues + 1) * kQueueStride;
+constexpr size_t kCounterBytes = (size_t)(kCostWordsAt + 2 * kCostClasses) * sizeof(unsigned int);
+static_assert(kCounterBytes % 256 == 0, "the chunk sums behind the counters stay 256-byte aligned");
+constexpr int kMaxOrderedItems = 1 << 19;     // frames cut into more items than this run in the natural order
+// A scene's own counters are followed by the cost of every item of the last launch and the order made of them
+// (kMaxOrderedItems words each); these word offsets are relative to RenderArgs::queue.
+constexpr int kItemCostFromQueue = (int)(kCounterBytes / sizeof(unsigned int)) - kQueueStride;
+constexpr int kItemOrderFromQueue = kItemCostFromQueue + kMaxOrderedItems;
+
+// Class of an item's cost (ticks of the 100 MHz clock it was open for): 2^CRT_COST_CLASS_BITS classes per power of two.
+#ifndef CRT_COST_CLASS_BITS
+#define CRT_COST_CLASS_BITS 2
+#endif
+__host__ __device__ __forceinline__ int cost_class(unsigned int ticks) {
+    const float f = (float)(ticks > 0u ? ticks : 1u);
+    unsigned int bits;
+    __builtin_memcpy(&bits, &f, 4);
+    const int k = (int)(bits >> (23 - CRT_COST_CLASS_BITS)) - (127 << CRT_COST_CLASS_BITS);
+    return k < 0 ? 0 : (k >= kCostClasses ? kCostClasses - 1 : k);
+}
 
 struct RenderArgs {
     DevScene sc;
@@ -93,6 +115,12 @@ struct RenderArgs {
     int spill_threads;
     unsigned int* queue;             // next work item (tile, chunk) to hand out; zero at launch
     // (kQueues counters, kQueueStride words apart, each handing out the items i with i % kQueues == its number)
+    // Launch order of the items (kept behind the counters, see kCostWordsAt ...: no further pointers to hold in
+    // registers).  order_mode 0: the n-th item handed out is item n.  1: the same, and every finished item leaves
+    // the time it was open in the cost array; the host turns them into the
+    // order of the next launch of the same frame, most expensive items first.  2: as 1, and the n-th item handed
+    // out is order[n].
+    int order_mode;
     int tiles_x, tiles_y, ntiles, pix_padded;
     int first_sample, samples, chunk_size, chunks;
     int prim_batch;                  // tree modes: lanes with leaf candidates that trigger a round of primitive tests
@@ -258,6 +286,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     // goes on with the next one for good; when all have run out the queue is empty.
     // (which counter, and how many have run out: flat mode keeps the two in LDS with the rest of the item)
     unsigned int queue_at = blockIdx.x % kQueues, queues_out = 0;
+    unsigned int fill_opened = 0, drain_opened = 0;               // (tree modes) when the two open items were taken from the queue
     if constexpr (kItemInLds) { if (lane == 0) { item_mem[8] = (int)queue_at; item_mem[9] = 0; } }
     auto fetch = [&]() {
         WorkItem w = {};
@@ -278,6 +307,14 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         if constexpr (kItemInLds) { if (lane == 0) { item_mem[8] = (int)at; item_mem[9] = (int)out; } }
         else { queue_at = at; queues_out = out; }
         w.valid = q < (unsigned int)item_count;
+        if (A.order_mode == 2 && w.valid) {
+            unsigned int v = 0;
+            if (lane == 0) v = A.queue[kItemOrderFromQueue + q];
+            q = __builtin_amdgcn_readfirstlane(v);
+        }
+        const unsigned int now = (unsigned int)wall_clock64();
+        if constexpr (kItemInLds) { if (lane == 0) item_mem[10] = (int)now; }
+        else fill_opened = now;
         const int chunk = (int)(q / (unsigned int)A.ntiles);
         const int tile = (int)q - chunk * A.ntiles;
         const int s0 = A.first_sample + chunk * A.chunk_size;
@@ -299,7 +336,11 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         return w;
     };
     // tile sums of one finished item -> HBM (lane = pixel of the tile), buffer cleared for the next item
-    auto flush = [&](int buffer, int tile, int chunk) {
+    auto flush = [&](int buffer, int tile, int chunk, unsigned int opened) {
+        if (A.order_mode != 0 && lane == 0) {
+            const unsigned int ticks = (unsigned int)wall_clock64() - opened;
+            A.queue[kItemCostFromQueue + chunk * A.ntiles + tile] = ticks;
+        }
         float* sums = acc + buffer * kTilePixels;
         float* out = A.partial + (size_t)chunk * kPasses * A.pix_padded + (size_t)tile * kTilePixels + lane;
         const size_t ps = A.pix_padded;
@@ -410,8 +451,8 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         if (draining) {
             const bool mine = alive && ((get_pixoff() >= kTilePixels) == ((fill_buffer ^ 1) != 0));
             if (!lanes_where(mine)) {
-                if constexpr (kItemInLds) flush(fill_buffer ^ 1, item_mem[6], item_mem[7]);
-                else flush(fill_buffer ^ 1, drain_tile, drain_chunk);
+                if constexpr (kItemInLds) flush(fill_buffer ^ 1, item_mem[6], item_mem[7], (unsigned int)item_mem[11]);
+                else flush(fill_buffer ^ 1, drain_tile, drain_chunk, drain_opened);
                 draining = false;
             }
         }
@@ -419,9 +460,9 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         if (fill.valid && fill.next >= fill.total && !draining) {
             draining = true;
             if constexpr (kItemInLds) {
-                if (lane == 0) { item_mem[6] = item_mem[4]; item_mem[7] = item_mem[5]; }
+                if (lane == 0) { item_mem[6] = item_mem[4]; item_mem[7] = item_mem[5]; item_mem[11] = item_mem[10]; }
             } else {
-                drain_tile = fill.tile; drain_chunk = fill.chunk;
+                drain_tile = fill.tile; drain_chunk = fill.chunk; drain_opened = fill_opened;
             }
             fill_buffer ^= 1;
             fill = fetch();
@@ -560,6 +601,56 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
 
     // one ray-count atomic per wave
     if (lane == 0) atomicAdd(A.ray_counter, (unsigned long long)rays);
+}
+
+// The launch order of the next frame: items by the class of their measured cost, most expensive class first
+// (within a class in no particular order).  The last items a launch hands out are then its cheapest, and the
+// waves run dry within the time one cheap item takes instead of one expensive one.  `classes` = items per class
+// (count_cost_classes), `placed` = zero on entry.  One thread per item, 4 items per thread.
+constexpr int kOrderItemsPerThread = 4;
+// (The classes are counted here, one addition per class and block, not by the render kernel item by item: the
+// items of a plain scene fall into a handful of classes, and a hundred thousand additions to a handful of
+// addresses take longer than the frame - the orthographic cube went from 1.3 to 1.7 ms.)
+__global__ __launch_bounds__(kBlock) void count_cost_classes(const unsigned int* cost, int n, unsigned int* classes) {
+    __shared__ unsigned int here[kCostClasses];
+    for (int k = threadIdx.x; k < kCostClasses; k += kBlock) here[k] = 0;
+    __syncthreads();
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * kOrderItemsPerThread;
+#pragma unroll
+    for (int k = 0; k < kOrderItemsPerThread; k++)
+        if (base + k < n) atomicAdd(&here[cost_class(cost[base + k])], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kCostClasses; k += kBlock)
+        if (here[k]) atomicAdd(&classes[k], here[k]);
+}
+__global__ __launch_bounds__(kBlock) void order_by_cost(const unsigned int* cost, int n, const unsigned int* classes, unsigned int* placed, unsigned int* order) {
+    __shared__ unsigned int here[kCostClasses], first[kCostClasses];
+    for (int k = threadIdx.x; k < kCostClasses; k += kBlock) here[k] = 0;
+    __syncthreads();
+    int cls[kOrderItemsPerThread];
+    unsigned int rank[kOrderItemsPerThread];
+    const int base = (blockIdx.x * kBlock + threadIdx.x) * kOrderItemsPerThread;
+#pragma unroll
+    for (int k = 0; k < kOrderItemsPerThread; k++) {
+        cls[k] = -1; rank[k] = 0;
+        if (base + k < n) {
+            cls[k] = cost_class(cost[base + k]);
+            rank[k] = atomicAdd(&here[cls[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kCostClasses; k += kBlock) {
+        unsigned int before = 0;                       // items of all more expensive classes
+        for (int j = k + 1; j < kCostClasses; j++) before += classes[j];
+        first[k] = before + (here[k] ? atomicAdd(&placed[k], here[k]) : 0u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOrderItemsPerThread; k++) {
+        if (cls[k] < 0) continue;
+        const unsigned int at = first[cls[k]] + rank[k];
+        if (at < (unsigned int)n) order[at] = (unsigned int)(base + k);
+    }
 }
 
 struct ResolveArgs {
@@ -1180,7 +1271,19 @@ struct crt_scene {
     bool ordered = false;            // walked in the reference's order (a primitive sticks out of its box)
     float* partial = nullptr;        // chunk sums, sized at creation for the largest launch of this scene
     size_t partial_bytes = 0;
-    unsigned long long* ray_counter = nullptr;   // [0] rays traced, [1] next work item
+    unsigned long long* ray_counter = nullptr;   // kCounterBytes (rays traced, work-item counters, cost classes), then the item costs and the item order
+    // Launch order by measured cost: what every item of the last launch cost, the order made from it, and the cut
+    // of the frame (tiles, chunks, bands) that order belongs to.
+    bool order_ready = false;
+    int order_key[6] = {0, 0, 0, 0, 0, 0};
+    // Whether that order pays is measured, not assumed (it gains up to a sixth where item costs differ widely and
+    // loses a few percent where they do not: neighbouring tiles no longer run at the same time and share fewer
+    // texels).  Launches of one cut of the frame: 0 natural order (nothing measured yet), 1 by cost (neither is
+    // timed: the first launches of a scene pay for cold caches and rising clocks), 2 and 4 natural order, 3 and 5 by
+    // cost, all four timed, 6... the order with the fastest timed launch.
+    int order_stage = 0, launched_stage = -1;
+    float by_cost_ms = 0.0f, natural_ms = 0.0f;
+    static constexpr int kOrderDecided = 6;
     unsigned long long* host_counter = nullptr;  // pinned: the ray count of the last launch lands here
     unsigned char* static_scratch = nullptr;     // this GPU's copy of `scratch` (crt_render_static)
     crt_scene_options opt = {};
@@ -1724,6 +1827,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     if (opt.general_kernel < 0 || opt.general_kernel > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->general_kernel must be 0 or 1");
     if (opt.flat_cuboids < 0 || opt.flat_cuboids > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..3");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
+    if (opt.item_order < 0 || opt.item_order > 2) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->item_order must be 0, 1 or 2");
     if (opt.exact_ties < 0 || opt.exact_ties > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->exact_ties must be 0 or 1");
     if (opt.work_items > (1 << 26)) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->work_items must not exceed 67 108 864");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
@@ -2279,7 +2383,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
-    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, kCounterBytes));
+    CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, kCounterBytes + (size_t)2 * kMaxOrderedItems * sizeof(unsigned int)));
     sc->spill_entries = std::max(0, need - (stack_entries - 1));       // one LDS row is the row of -1 below the stacks
     sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), std::max(CRT_TREE_WAVES_PER_SIMD, CRT_TREE_BASIC_WAVES_PER_SIMD)), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
     if (sc->spill_entries > 0) {
@@ -2509,6 +2613,7 @@ struct ScratchView {
     unsigned long long* counters;    // kCounterBytes: rays traced, then the work-item counters
     float* partial;
     size_t partial_bytes;
+    bool keeps_order;                // the scene's own scratch: item costs are recorded and order the next launch
 };
 
 static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done, const ScratchView& S, const char* who,
@@ -2558,6 +2663,21 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     A.ray_counter = S.counters;
     A.queue = reinterpret_cast<unsigned int*>(S.counters) + kQueueStride;
     CRT_HIP(hipMemsetAsync(S.counters, 0, kCounterBytes, sc->stream));
+    // Launch order: the items of this cut of the frame, most expensive first, as the last launch of the same cut
+    // measured them (the first launch of a cut runs in the natural order, tile after tile and chunk after chunk).
+    const long long items_ll = (long long)plan.ntiles * plan.chunks;
+    const int order_key[6] = {plan.ntiles, plan.chunks, plan.chunk_size, bands.rows, bands.index, bands.count};
+    const bool fused = !(sc->wavefront && kernel_mode(sc) == kModeTreeGlobal);
+    const bool may_order = S.keeps_order && fused && sc->opt.item_order != 1 && !sc->opt.deterministic && items_ll <= kMaxOrderedItems;
+    const bool same_cut = sc->order_ready && std::equal(order_key, order_key + 6, sc->order_key);
+    if (!same_cut) sc->order_stage = 0;
+    // (by cost only where that is at least 0.5 % faster: sorting the costs takes 10 to 15 us of every launch)
+    const bool decided = sc->opt.item_order == 0 && sc->order_stage >= crt_scene::kOrderDecided;
+    const bool by_cost = sc->opt.item_order == 2 || (!decided && (sc->order_stage & 1)) || (decided && sc->by_cost_ms < 0.995f * sc->natural_ms);
+    // (once the natural order has won, the item costs are no longer recorded or sorted)
+    const bool keeps_order = may_order && !(decided && !by_cost);
+    A.order_mode = !keeps_order ? 0 : (same_cut && by_cost ? 2 : 1);
+    sc->launched_stage = keeps_order ? sc->order_stage : -1;
     // persistent waves: as many blocks as the chip holds at once (or fewer when there is less work)
     const long long items = (long long)plan.ntiles * plan.chunks;
     int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc), variant_features(sc)) / kWaves);   // 4 SIMDs per CU
@@ -2568,6 +2688,20 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     int rc = wavefront ? launch_wavefront(sc, A, plan, bands) : launch_fused(sc, A, grid);
     if (rc != CRT_OK) return rc;
     CRT_HIP(hipEventRecord(sc->ev_mid, sc->stream));
+    if (keeps_order) {
+        const int n = (int)items_ll, per_block = kBlock * kOrderItemsPerThread;
+        unsigned int* words = reinterpret_cast<unsigned int*>(S.counters);
+        hipLaunchKernelGGL(count_cost_classes, dim3((n + per_block - 1) / per_block), dim3(kBlock), 0, sc->stream, (const unsigned int*)(A.queue + kItemCostFromQueue), n, words + kCostWordsAt);
+        hipLaunchKernelGGL(order_by_cost, dim3((n + per_block - 1) / per_block), dim3(kBlock), 0, sc->stream, (const unsigned int*)(A.queue + kItemCostFromQueue), n,
+                           (const unsigned int*)(words + kCostWordsAt), words + kCostWordsAt + kCostClasses, A.queue + kItemOrderFromQueue);
+        CRT_HIP(hipGetLastError());
+        std::copy(order_key, order_key + 6, sc->order_key);
+        sc->order_ready = true;
+        if (sc->order_stage < crt_scene::kOrderDecided) sc->order_stage++;
+    } else if (S.keeps_order && !may_order) {
+        sc->order_ready = false;
+        sc->order_stage = 0;
+    }
     ResolveArgs R;
     R.partial = S.partial;
     R.color = buf->color(); R.albedo = buf->albedo(); R.emission = buf->emission(); R.normal = buf->normal();
@@ -2590,7 +2724,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
 int crt_render_launch(crt_scene* sc, crt_buffers* buf, int first_sample, int samples, int fold_done) {
     crt::clear_error();
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_launch: null argument");
-    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes};
+    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes, true};
     return launch_render(sc, buf, first_sample, samples, fold_done, S, "crt_render_launch");
 }
 
@@ -2604,7 +2738,7 @@ int crt_band_row_count(int height, int band_rows, int band_index, int band_count
 int crt_render_bands_launch(crt_scene* sc, crt_buffers* own, int first_sample, int samples, int band_rows, int band_index, int band_count) {
     crt::clear_error();
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_render_bands_launch: null argument");
-    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes};
+    const ScratchView S = {sc->ray_counter, sc->partial, sc->partial_bytes, true};
     return launch_render(sc, own, first_sample, samples, 0, S, "crt_render_bands_launch", Bands{band_rows, band_index, band_count});
 }
 
@@ -2649,6 +2783,10 @@ int crt_render_finish(crt_scene* sc, float* kernel_ms_out, uint64_t* rays_out) {
     }
     CRT_HIP(hipEventElapsedTime(&sc->last_trace_ms, sc->ev_start, sc->ev_mid));
     CRT_HIP(hipEventElapsedTime(&sc->last_resolve_ms, sc->ev_mid, sc->ev_stop));
+    if (sc->launched_stage == 2) sc->natural_ms = sc->last_trace_ms;
+    if (sc->launched_stage == 3) sc->by_cost_ms = sc->last_trace_ms;
+    if (sc->launched_stage == 4) sc->natural_ms = std::min(sc->natural_ms, sc->last_trace_ms);
+    if (sc->launched_stage == 5) sc->by_cost_ms = std::min(sc->by_cost_ms, sc->last_trace_ms);
     if (rays_out) *rays_out = *sc->host_counter;
     return CRT_OK;
 }
@@ -2737,7 +2875,7 @@ int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_
     // launch_render() cuts the frame into as many sample chunks as fit the array and refuses an
     // image whose sums of a single chunk (56 bytes per padded pixel) do not
     const ScratchView S = {reinterpret_cast<unsigned long long*>(sc->static_scratch),
-                           reinterpret_cast<float*>(sc->static_scratch + kStaticCounterBytes), kStaticScratchBytes - kStaticCounterBytes};
+                           reinterpret_cast<float*>(sc->static_scratch + kStaticCounterBytes), kStaticScratchBytes - kStaticCounterBytes, false};
     int rc = launch_render(sc, buf, samples_done, samples, samples_done, S, "crt_render_static");
     if (rc != CRT_OK) return rc;
     float ms = 0.0f;

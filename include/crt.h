@@ -205,6 +205,7 @@ typedef struct crt_scene_options {
                                  tenth slower.  0 (default): the nearer hit wins, exact ties by visiting rank; differs
                                  from the reference in about one path in 10^8 (a ray through an edge that lies in a
                                  box face)                                                             */
+    int32_t item_order;       /* described in crt_dev.h (0 = default)                                   */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 

@@ -29,7 +29,16 @@ extern "C" {
  *                   (default; same hits, fewer operations), 2 = every slot on its own, 3 = tested together, but the
  *                   far faces like any other candidate (for comparison)
  *   general_kernel  1: always run the kernel variant compiled for every scene feature (spheres, textures, metal and
- *                   glass, camera kinds ...) instead of the one compiled for just what the scene contains; same results */
+ *                   glass, camera kinds ...) instead of the one compiled for just what the scene contains; same results
+ *   item_order      the order in which a frame's work items (pixel tile x sample chunk) are handed to the waves.
+ *                   By cost: most expensive first, by the time each took in the last launch of the same frame (same
+ *                   tiles, chunks and bands); the launch then ends on its cheapest items and the GPU runs dry in a
+ *                   fraction of the time.  Natural: tile after tile and chunk after chunk.  Which samples an item
+ *                   holds does not change, so the sums are the same whatever the order.
+ *                   0 = measured: the first six launches of a frame alternate between the natural order and the order
+ *                   by cost, the last four of them are timed, and from the seventh on the launches use the order of
+ *                   the fastest timed one (by cost only if by at least 0.5 %); 1 = always natural; 2 = by cost from
+ *                   the second launch on.  (Deterministic renders and crt_render_static always use the natural order.) */
 
 /* Development aid: loop-occupancy counters of a library built with -DCRT_PROFILE
  * (128 values: site k < 8 -> [2k] wave-level executions, [2k+1] active lanes; flat mode: [16+n] rays

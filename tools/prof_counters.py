@@ -38,3 +38,10 @@ if tot:
     for k, n in enumerate(secs_names):
         print(f"  {n:8s} {int(out[32 + k]) / tot * 100:6.2f} %   raw {int(out[32 + k])}")
     print(f"  total clocks {tot:.0f}, kernel {secs * 1e3:.2f} ms")
+    if int(out[43]):
+        waves = int(out[43])
+        first_start = (~int(out[40])) & 0xFFFFFFFFFFFFFFFF
+        span = (int(out[41]) - first_start) / 100.0          # microseconds (100 MHz counter)
+        mean_life = int(out[42]) / waves / 100.0
+        print(f"  waves {waves}: first start to last end {span:.1f} us, last start {(int(out[44]) - first_start) / 100.0:.1f} us after the first, "
+              f"mean wave lifetime {mean_life:.1f} us = {mean_life / span * 100:.1f} % of the span")
