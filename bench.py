@@ -168,8 +168,11 @@ def roofline_block(scene, rays_per_launch, kernel_ms, resolve_ms, with_traffic):
 
 
 # The BASELINE configurations besides the headline one: (scene file, timed frames, warmup frames).
-OTHER_CONFIGS = (("orthographic.yaml", 10, 2), ("obj.yaml", 5, 1), ("materials.yaml", 5, 1),
-                 ("materials_hdr.yaml", 5, 1), ("mesh1m.yaml", 2, 1))
+# (six warmup frames: a scene's first six launches alternate between two orders of its work items, timed by the
+# library, before it settles on the faster one)
+SETTLE_FRAMES = 6
+OTHER_CONFIGS = (("orthographic.yaml", 10, SETTLE_FRAMES), ("obj.yaml", 5, SETTLE_FRAMES), ("materials.yaml", 5, SETTLE_FRAMES),
+                 ("materials_hdr.yaml", 5, SETTLE_FRAMES), ("mesh1m.yaml", 2, SETTLE_FRAMES))
 
 
 def measure_config(crt, torch, scene_name, steps, warmup):
@@ -458,12 +461,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed: the frames in which every scene copy settles the order of its work items, then the W warmup steps
+    settle = SETTLE_FRAMES * len(scenes)
+    run(settle)
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
     rays_rank, trace_ms, resolve_ms = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_variant = sc.describe()
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -493,7 +500,8 @@ def main():
         else:
             how = (f"sample ranges per rank ({args.scaling}), one all-reduce of 14*W*H floats per frame, overlapped with the next frame")
         config = {"workload": f"{args.scene} {W}x{H}, {total_spp} spp in total, {bounces} bounces",
-                  "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps}
+                  "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps,
+                  "settle_frames": settle, "kernel_variant": kernel_variant}
         if single_gpu_ms is not None:
             config["sharding_choice"] = {"single_gpu_frame_ms_measured": round(single_gpu_ms, 3), "predicted_frame_ms": predicted,
                                          "chosen": sharding}

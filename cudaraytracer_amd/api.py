@@ -182,8 +182,8 @@ class Scene:
     def describe(self):
         """Kernel variant of the next render: 'mode=flat slots=18 groups=2 reciprocal=newton ...'."""
         self.upload()
-        buf = C.create_string_buffer(256)
-        _check(_lib.crt_scene_describe(self._dev, buf, 256))
+        buf = C.create_string_buffer(384)
+        _check(_lib.crt_scene_describe(self._dev, buf, 384))
         return buf.value.decode()
 
     def set_mode(self, mode):

@@ -2535,14 +2535,20 @@ int crt_scene_describe(crt_scene* sc, char* text, int size) {
     crt::clear_error();
     if (!sc) return crt::set_error(CRT_ERR_INVALID, "crt_scene_describe: null scene");
     static const char* const names[3] = {"tree_hbm", "tree_lds", "flat"};
-    char line[256];
+    char line[320];
+    // items=: how the work items of the last launch were ordered, and (measured choice) what the timed launches took
+    char items[96];
+    if (sc->opt.item_order == 1 || sc->opt.deterministic) std::snprintf(items, sizeof(items), "natural");
+    else if (sc->opt.item_order == 2) std::snprintf(items, sizeof(items), "by-cost");
+    else if (sc->order_stage < crt_scene::kOrderDecided) std::snprintf(items, sizeof(items), "measuring(%d/%d)", sc->order_stage, crt_scene::kOrderDecided);
+    else std::snprintf(items, sizeof(items), "%s(natural %.3f ms, by cost %.3f ms)", sc->by_cost_ms < 0.995f * sc->natural_ms ? "by-cost" : "natural", (double)sc->natural_ms, (double)sc->by_cost_ms);
     // far=: candidate bits of the cuboid faces that are tested last (world group, rotated groups 1 and 2)
     unsigned world_far = 0;
     for (int a = 0; a < 3; a++) world_far |= sc->flat.world_face_a[a] | sc->flat.world_face_b[a];
-    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%03x slots=%d cuboids=%d groups=%d far=%x/%x/%x margin=%g reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s%s", names[kernel_mode(sc)], sc->features,
+    const int n = std::snprintf(line, sizeof(line), "mode=%s features=0x%03x slots=%d cuboids=%d groups=%d far=%x/%x/%x margin=%g reciprocal=%s stack=%d+%d nodes=%d objects=%d order=%s items=%s%s", names[kernel_mode(sc)], sc->features,
                                 sc->flat.slot_count, sc->flat.cuboid_end[kMaxFlatGroups], sc->flat.groups, world_far, sc->flat.far_shift[1] >= 0 ? 63u << sc->flat.far_shift[1] : 0u,
                                 sc->flat.far_shift[2] >= 0 ? 63u << sc->flat.far_shift[2] : 0u, (double)sc->far_margin, sc->dev.fast_rcp ? "newton" : "ieee", sc->stack_entries, sc->spill_entries,
-                                sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free",
+                                sc->dev.node_count, sc->dev.object_count, sc->ordered ? "reference" : "free", items,
                                 sc->wavefront && kernel_mode(sc) == kModeTreeGlobal ? " pipeline=wavefront" : "");
     if (text && size > 0) std::snprintf(text, (size_t)size, "%s", line);
     return n;
