@@ -178,20 +178,22 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// (kept as ONE word, pos = state + draws * PHI modulo 2^32: a draw is an addition and a hash, and a path carries
+// one register instead of two)
+constexpr uint32_t kRngStep = 0x9E3779B9u;
 struct Rng {
-    uint32_t state, draws;
+    uint32_t pos;
     __device__ __forceinline__ void init(int pixel_index, int sample_number) {
         uint32_t s = lowbias32(1984u + (uint32_t)pixel_index);
-        state = lowbias32(s + (uint32_t)sample_number * 0x9E3779B9u);
-        draws = 0;
+        pos = lowbias32(s + (uint32_t)sample_number * kRngStep);
     }
     __device__ __forceinline__ float uniform() {
-        draws++;
-        uint32_t x = lowbias32(state + draws * 0x9E3779B9u);
+        pos += kRngStep;
+        uint32_t x = lowbias32(pos);
         return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);
     }
     // A draw whose value is never read only advances the counter.
-    __device__ __forceinline__ void skip(uint32_t n) { draws += n; }
+    __device__ __forceinline__ void skip(uint32_t n) { pos += n * kRngStep; }
     __device__ __forceinline__ V3 range3(float lo, float hi) {       // vec3::random(min,max) vec3.cuh:191
         float x = lo + (hi - lo) * uniform();
         float y = lo + (hi - lo) * uniform();
@@ -1339,7 +1341,7 @@ __device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x
 //
 // A lane accepts its first candidate with probability pi/6, so a loop that runs until the last
 // of 64 lanes has accepted takes about 7 rounds with a quarter of the lanes active.  Candidate c
-// of a lane is a pure function of (rng.state, rng.draws + 3c), so ANY lane can evaluate it:
+// of a lane is a pure function of its stream position advanced by 3c draws, so ANY lane can evaluate it:
 // after every lane has tried its own first candidate, the lanes still pending publish their
 // stream position in LDS and all 64 lanes evaluate the next m candidates of each of them in
 // one round (m = 64 / pending, at most 8).  The pending lane takes the FIRST accepted candidate
@@ -1347,9 +1349,9 @@ __device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x
 // so the result and the draw count are identical to the sequential sampler's.
 // Must be called by the whole wave in uniform control flow; `pub` (128 words) and `res`
 // (192 floats) are this wave's LDS scratch.
-__device__ __forceinline__ V3 candidate_point(uint32_t state, uint32_t base) {
+__device__ __forceinline__ V3 candidate_point(uint32_t pos) {
     Rng r;
-    r.state = state; r.draws = base;
+    r.pos = pos;
     return r.range3(-1.0f, 1.0f);
 }
 __device__ __forceinline__ bool sample_accepted(V3 p, bool in_sphere) {
@@ -1366,14 +1368,16 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int FAST = 0>
+// (IN_SPHERE_TOO = false: every caller asks for unit vectors, and the flag that tells the two kinds apart is not published)
+template <int FAST = 0, bool IN_SPHERE_TOO = true>
 __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng& rng, uint32_t* pub, float* res, int lane) {
+    if constexpr (!IN_SPHERE_TOO) in_sphere = false;
     V3 out = v3(0.0f, 0.0f, 0.0f);
     bool pending = false;
     if (need) {
         CRT_PROF(kProfReject);
-        out = candidate_point(rng.state, rng.draws);
-        rng.draws += 3;
+        out = candidate_point(rng.pos);
+        rng.skip(3);
         pending = !sample_accepted(out, in_sphere);
     }
     unsigned long long mask = lanes_where(pending);
@@ -1384,16 +1388,16 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
         const int m = 1 << log2m;
         const int rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
         if (pending) {
-            pub[2 * rank] = rng.state;
-            pub[2 * rank + 1] = rng.draws | (in_sphere ? 0x80000000u : 0u);
+            pub[2 * rank] = rng.pos;
+            if constexpr (IN_SPHERE_TOO) pub[2 * rank + 1] = in_sphere ? 1u : 0u;
         }
         wave_lds_sync();
         const int target = lane >> log2m, c = lane & (m - 1);
         bool ok = false;
         if (target < pending_count) {
-            const uint32_t st = pub[2 * target], word = pub[2 * target + 1];
-            const V3 p = candidate_point(st, (word & 0x7fffffffu) + 3u * (uint32_t)c);
-            ok = sample_accepted(p, (word >> 31) != 0);
+            const uint32_t at = pub[2 * target];
+            const V3 p = candidate_point(at + (uint32_t)c * (3u * kRngStep));
+            ok = sample_accepted(p, IN_SPHERE_TOO && pub[2 * target + 1] != 0u);
             res[3 * lane] = p.x; res[3 * lane + 1] = p.y; res[3 * lane + 2] = p.z;
         }
         const unsigned long long okmask = lanes_where(ok);
@@ -1404,10 +1408,10 @@ __device__ __forceinline__ V3 coop_sphere_sample(bool need, bool in_sphere, Rng&
                 const int first = __builtin_ctz(sub);
                 const int src = (rank << log2m) + first;
                 out = v3(res[3 * src], res[3 * src + 1], res[3 * src + 2]);
-                rng.draws += 3u * (uint32_t)(first + 1);
+                rng.skip(3u * (uint32_t)(first + 1));
                 pending = false;
             } else {
-                rng.draws += 3u * (uint32_t)m;
+                rng.skip(3u * (uint32_t)m);
             }
         }
         wave_lds_sync();                                    // the next round overwrites pub and res

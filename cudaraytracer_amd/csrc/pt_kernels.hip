@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
     };
     int bounces = 0;
     Rng rng;
-    rng.state = 0; rng.draws = 0;
+    rng.pos = 0;
     TreeState ts;                                                 // tree modes: the lane's walk in progress
     ts.begin(INFINITY, sc.root_entry);
     bool walking = false;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
         }
         // the sphere sample of a diffuse or metal bounce, drawn by the whole wave together
         CRT_CLOCK(clk, kSecSample, sf.p.x);
-        const V3 rv = coop_sphere_sample<FAST>(mat_type == 0 || ((FEAT & kFeatMaterials) && mat_type == 1), (FEAT & kFeatMaterials) && mat_type == 1, rng, coop_pub, coop_res, lane);
+        const V3 rv = coop_sphere_sample<FAST, (FEAT & kFeatMaterials) != 0>(mat_type == 0 || ((FEAT & kFeatMaterials) && mat_type == 1), (FEAT & kFeatMaterials) && mat_type == 1, rng, coop_pub, coop_res, lane);
         V3 rv_dep = rv;
         CRT_CLOCK(clk, kSecScatter, rv_dep.x);
         if (ready) {
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void resolve_passes(ResolveArgs R) {
 // reproducible bit for bit with per-path records instead of per-sample chunk sums.
 struct WfQueue {
     float4 *ray0, *ray1;     // (o.xyz, d.x)  (d.y, d.z, time, -)
-    float4 *st0, *st1;       // (throughput.xyz, rng.state)  (pending albedo.xyz, rng.draws)
+    float4 *st0, *st1;       // (throughput.xyz, rng.pos)  (pending albedo.xyz, -)
     uint2* meta;             // (path id within the batch, bounces so far)
     unsigned int* count;     // [segments] live slots at the front of each segment
 };
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate(WfArgs A) {
             Ray ray;
             ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
             Rng rng;
-            rng.state = 0; rng.draws = 0;
+            rng.pos = 0;
             if (p < total && sc.max_bounces > 0) {
                 // path id = (tile * samples + sample) * 32 + pixel of the tile
                 const int pix = (int)(p % kWfTilePixels);
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(kBlock) void wf_generate(WfArgs A) {
             if (live) {
                 A.cur.ray0[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
                 A.cur.ray1[slot] = make_float4(ray.d.y, ray.d.z, ray.time, 0.0f);
-                A.cur.st0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.state));
-                A.cur.st1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng.draws));
+                A.cur.st0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.pos));
+                A.cur.st1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 A.cur.meta[slot] = make_uint2((unsigned int)p, 0u);
             }
         }
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
         ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.time = 0.0f;
         V3 throughput = v3(1, 1, 1), pend_albedo = v3(0, 0, 0);
         Rng rng;
-        rng.state = 0; rng.draws = 0;
+        rng.pos = 0;
         unsigned int path = 0, bounces = 0;
         Hit h;
         h.t = 0.0f; h.obj = -1; h.bu = 0.0f; h.bv = 0.0f;
@@ -946,8 +946,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
             const float4 r0 = A.cur.ray0[in], r1 = A.cur.ray1[in], s0 = A.cur.st0[in], s1 = A.cur.st1[in], hh = A.hit[in];
             const uint2 m = A.cur.meta[in];
             ray.o = v3(r0.x, r0.y, r0.z); ray.d = v3(r0.w, r1.x, r1.y); ray.time = r1.z;
-            throughput = v3(s0.x, s0.y, s0.z); rng.state = __float_as_uint(s0.w);
-            pend_albedo = v3(s1.x, s1.y, s1.z); rng.draws = __float_as_uint(s1.w);
+            throughput = v3(s0.x, s0.y, s0.z); rng.pos = __float_as_uint(s0.w);
+            pend_albedo = v3(s1.x, s1.y, s1.z);
             path = m.x; bounces = m.y;
             h.t = hh.x; h.obj = __float_as_int(hh.y); h.bu = hh.z; h.bv = hh.w;
         }
@@ -1018,8 +1018,8 @@ __global__ __launch_bounds__(kBlock) void wf_shade(WfArgs A) {
         if (alive) {
             A.next.ray0[out] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
             A.next.ray1[out] = make_float4(ray.d.y, ray.d.z, ray.time, 0.0f);
-            A.next.st0[out] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.state));
-            A.next.st1[out] = make_float4(pend_albedo.x, pend_albedo.y, pend_albedo.z, __uint_as_float(rng.draws));
+            A.next.st0[out] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.pos));
+            A.next.st1[out] = make_float4(pend_albedo.x, pend_albedo.y, pend_albedo.z, 0.0f);
             A.next.meta[out] = make_uint2(path, bounces + 1u);
         }
         }
