@@ -254,9 +254,10 @@ int crt_render(crt_scene* sc, crt_buffers* buf, int samples, int samples_done,
  * hipMalloc/hipFree.  Limits: one chunk of sums = 56 bytes per pixel of the image padded to 8x8
  * (8x4 in the tree modes) tiles must fit, i.e. at most about 1.19 M pixels (1000x1000 fits,
  * 1280x1024 does not) - larger images get CRT_ERR_UNSUPPORTED; with fewer chunks than crt_render()
- * would use, the launch has fewer work items and balances worse (1000x1000: 1 chunk instead of 5).
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two scenes, two
- * threads) race.  Sums are added in a different grouping than in crt_render() when the chunk
+ * would use, the launch has fewer work items and balances worse (1000x1000: 1 chunk instead of 4).
+ * Every call on a GPU shares that GPU's array, which keeps the last call's contents (counters are cleared at the start of
+ * a call): two calls that overlapped on one GPU (two scenes, two threads) would race on it, so a call that finds another
+ * one running on its GPU returns CRT_ERR_INVALID.  The work items are always handed out in the natural order.  Sums are added in a different grouping than in crt_render() when the chunk
  * counts differ, so results agree to float summation order, and bit for bit when both calls use one
  * sample per chunk (small images, or crt_scene_options.deterministic). */
 int crt_render_static(crt_scene* sc, crt_buffers* buf, int samples, int samples_done,

@@ -57,7 +57,7 @@ def test_static_scratch_progressive_calls_fold_like_crt_render(crt):
 
 
 def test_static_scratch_full_size_frame_within_summation_order(crt):
-    # 1000x1000: crt_render cuts 8 samples into 5 chunks, the 64 MiB array holds one chunk, so the
+    # 1000x1000: crt_render cuts 8 samples into 4 chunks, the 64 MiB array holds one chunk, so the
     # per-pixel sums are grouped differently: same samples, float summation order differs.
     (ref, ref_rays), (got, got_rays) = _render_both(crt, "cornell_box.yaml", 1000, 1000, 8)
     assert got_rays == ref_rays
