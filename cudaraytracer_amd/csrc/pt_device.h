@@ -1092,9 +1092,6 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
     // rotated groups' cuboids, and those only for rays whose closest hit so far is not already in front of them
     // (flat_cuboid_shared(): a ray that crosses a box meets two of its faces, the far one to no purpose).
     far |= far0;
-#ifdef CRT_DEBUG_FAR
-    if (blockIdx.x == 0 && threadIdx.x < 8) printf("lane %d cand %x far %x far0 %x wf %x safe0 %g safe1 %g safe2 %g inv %g %g %g\n", (int)threadIdx.x, cand_lo, far, far0, world_faces, safe0, safe1, safe2, inv0.x, inv0.y, inv0.z);
-#endif
     far &= cand_lo;
     cand_lo ^= far;
 #if defined(CRT_PROFILE) && !defined(CRT_PROFILE_CLOCK)
@@ -1108,10 +1105,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
             for (unsigned m = cand_lo | far; m; m &= m - 1u) atomicAdd(&g_prof[64 + __builtin_ctz(m)], 1ull);
     }
 #endif
-#ifndef CRT_NO_SPHERE_PHASE
-#define CRT_NO_SPHERE_PHASE 0
-#endif
-    if constexpr ((FEAT & kFeatSphere) != 0 && !CRT_NO_SPHERE_PHASE) {
+    if constexpr ((FEAT & kFeatSphere) != 0) {
         unsigned spheres = cand_lo & F.sphere_bits;
         cand_lo ^= spheres;
         while (spheres) {
@@ -1127,7 +1121,7 @@ __device__ __forceinline__ Hit traverse_flat(const FlatLds& L, const FlatView& F
         if (!(FEAT & kFeatWide) || cand_lo) { bit = __builtin_ctz(cand_lo); cand_lo &= cand_lo - 1u; }
         else { bit = 32 + __builtin_ctz(cand_hi); cand_hi &= cand_hi - 1u; }
         // (beyond 32 slots the high word may hold spheres)
-        if constexpr ((FEAT & kFeatWide) != 0 || (CRT_NO_SPHERE_PHASE && (FEAT & kFeatSphere) != 0)) test_slot(bit, SlotKind<kSlotAny>());
+        if constexpr ((FEAT & kFeatWide) != 0) test_slot(bit, SlotKind<kSlotAny>());
         else test_slot(bit, SlotKind<kSlotTri>());
     };
     while (cand_lo | cand_hi | far) {
