@@ -516,10 +516,12 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             fill.next += __builtin_popcountll(free_mask);
         }
         CRT_CLOCK(clk, kSecOther, ray.o.x);
-        if (!lanes_where(alive)) {
-            if (!fill.valid && !draining) break;                  // queue empty and everything flushed
-            continue;
-        }
+        // (The rest of the round under an `if`, not skipped with a `continue`: with two ways back to the top of the loop the
+        // compiler kept the path state in one set of registers up to here and in another from here on and copied some twenty
+        // values from one to the other and back in every round - Cornell 7.10 -> 6.91 ms, the normal-map scene -5 %.)
+        const bool any_alive = lanes_where(alive) != 0ull;
+        if (!any_alive && !fill.valid && !draining) break;        // queue empty and everything flushed
+        if (any_alive) {
         Hit h;
         h.t = 0.0f; h.obj = -1; h.bu = 0.0f; h.bv = 0.0f;
         Surface sf = {};
@@ -624,6 +626,7 @@ __global__ __launch_bounds__(kBlock, waves_per_simd(MODE, FEAT)) void render_fus
             }
         }
         CRT_CLOCK(clk, kSecOther, throughput.x);
+        }
     }
     clk.flush();
 
