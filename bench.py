@@ -277,11 +277,19 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=50, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-configs", action="store_true", help="N = 1, headline scene: skip the other BASELINE configurations")
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1, strong scaling: after the timed region rank 0 renders the whole frame alone and compares it with the "
+                         "image the ranks produced together (largest difference in the line; non-zero exit beyond 1e-5 relative)")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks as child processes even for one GPU (rehearses the parent / child path and the collectives on a one-GPU machine)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
+
+    if os.environ.get("CRT_BENCH_TRACE_AFTER"):
+        # debugging aid: every process prints where it stands after that many seconds and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CRT_BENCH_TRACE_AFTER"]), exit=True)
 
     launched = "RANK" in os.environ
     if not launched and (args.gpus > 1 or args.launch):
@@ -307,6 +315,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # CRT_BENCH_SHARED_GPU=1 (a rehearsal, never a measurement): the ranks share the visible GPUs and
+    # talk over gloo (RCCL takes one rank per device), so that a one-GPU machine can walk through the
+    # N-rank control flow: the split, the rotation of the buffer sets, the order of the collectives
+    shared_gpu = os.environ.get("CRT_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank %= torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -317,7 +331,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if rank == 0:
         ensure_assets(args.scene)
@@ -355,7 +372,7 @@ def main():
                 # on every rank (after one untimed frame) and take the slowest
                 probe = crt.create_buffer(sc)
                 crt.render(sc, probe)
-                t = torch.tensor([crt.render(sc, probe) * 1e3], dtype=torch.float64, device="cuda")
+                t = torch.tensor([crt.render(sc, probe) * 1e3], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
                 probe.close()
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 single_gpu_ms = float(t.item())
@@ -402,10 +419,29 @@ def main():
     torch.cuda.synchronize()
     pending = [None] * depth
 
+    class HostStagedCollective:
+        """Shared-GPU rehearsal only: the collective over gloo on host copies, carried out where the
+        caller waits for it (every rank waits for its collectives in the same order)."""
+
+        def __init__(self, slot):
+            self.slot = slot
+
+        def wait(self):
+            if sharding == "tiles":
+                mine, everyone = own[self.slot].cpu(), torch.empty(world * stride, dtype=torch.float32)
+                dist.all_gather_into_tensor(everyone, mine)
+                gathered[self.slot].copy_(everyone)
+            else:
+                mean = passes[self.slot].cpu()
+                multi_gpu.combine_means(mean, count, total_spp, dist)
+                passes[self.slot].copy_(mean)
+
     def start_collective(slot):
         if not distributed:
             return
-        if sharding == "tiles":
+        if shared_gpu:
+            pending[slot] = HostStagedCollective(slot)
+        elif sharding == "tiles":
             pending[slot] = multi_gpu.gather_bands_async(own[slot], gathered[slot], dist)
         else:
             pending[slot] = multi_gpu.combine_means_async(passes[slot], count, total_spp, dist)
@@ -472,11 +508,44 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_variant = sc.describe()
 
+    check = None
+    if args.check and distributed and args.scaling == "strong" and rank == 0:
+        # the frame the ranks produced together against the same frame rendered here alone (outside the timed region)
+        import numpy as np
+        together = (image if sharding == "tiles" else passes[(args.steps - 1) % depth]).cpu().numpy()
+        alone = crt.create_buffer(sc)
+        alone_seconds = crt.render(sc, alone)
+        alone_rays = crt.api.last_ray_count
+        host = alone.download()
+        alone.close()
+        flat = np.concatenate([host[k].ravel() for k in ("color", "albedo", "emission", "normal", "depth", "opacity")])
+        both = np.isfinite(flat) & np.isfinite(together)
+        # (the N-rank frame groups a pixel's samples differently - per rank, per band - so sums differ in their last bits)
+        diff = np.abs(flat[both] - together[both])
+        check = {"max_abs_difference": float(diff.max()) if both.any() else 0.0,
+                 "max_relative_difference": float((diff / np.maximum(1.0, np.abs(flat[both]))).max()) if both.any() else 0.0,
+                 "bit_equal_fraction": float(np.mean(flat.view(np.uint32) == together.view(np.uint32))),
+                 "non_finite_agree": bool(np.array_equal(np.isfinite(flat), np.isfinite(together)))}
+        # which image rows differ by more than rounding (of the colour pass), and whose bands they are under the tile split
+        colour = np.abs(flat[:3 * W * H] - together[:3 * W * H]).reshape(H, W * 3).max(axis=1)
+        bad_rows = np.nonzero(~(colour <= 1e-4))[0]
+        check["rows_off"] = int(bad_rows.size)
+        if bad_rows.size:
+            check["rows_off_first"] = [int(r) for r in bad_rows[:8]]
+            check["ranks_of_rows_off"] = sorted({int((r // band_rows) % world) for r in bad_rows})
+            off = bad_rows[len(bad_rows) // 2]
+            check["colour_of_a_row_off"] = {"row": int(off), "alone_mean": float(np.abs(flat[:3 * W * H].reshape(H, W * 3)[off]).mean()),
+                                            "together_mean": float(np.abs(together[:3 * W * H].reshape(H, W * 3)[off]).mean())}
+            check["scene_after_the_single_render"] = sc.describe()
+            check["single_render"] = {"seconds": alone_seconds, "rays": int(alone_rays), "nonzero_fraction": float(np.mean(flat != 0.0))}
+            check["together_nonzero_fraction"] = float(np.mean(together != 0.0))
+
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        where = "cpu" if shared_gpu else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=where)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        rr = torch.tensor([rays_rank], dtype=torch.int64, device="cuda")
+        rr = torch.tensor([rays_rank], dtype=torch.int64, device=where)
         dist.all_reduce(rr)
         rays_total = int(rr.item())
     else:
@@ -502,6 +571,10 @@ def main():
         config = {"workload": f"{args.scene} {W}x{H}, {total_spp} spp in total, {bounces} bounces",
                   "spp_this_rank": count, "sharding": how, "rays_per_step": rays_total // args.steps,
                   "settle_frames": settle, "kernel_variant": kernel_variant}
+        if shared_gpu:
+            config["rehearsal"] = "the ranks share the visible GPUs and talk over gloo: control flow only, not a measurement"
+        if check is not None:
+            config["check_against_single_render"] = check
         if single_gpu_ms is not None:
             config["sharding_choice"] = {"single_gpu_frame_ms_measured": round(single_gpu_ms, 3), "predicted_frame_ms": predicted,
                                          "chosen": sharding}
@@ -533,6 +606,8 @@ def main():
 
     if distributed:
         dist.destroy_process_group()
+    if check is not None and (check["max_relative_difference"] > 1e-5 or not check["non_finite_agree"]):
+        raise SystemExit(f"bench.py: the image of {world} ranks differs from the single render: {check}")
 
 
 if __name__ == "__main__":

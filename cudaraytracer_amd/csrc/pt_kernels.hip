@@ -2414,6 +2414,8 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     blob.bytes.resize((blob.bytes.size() + 255) & ~size_t(255));
     CRT_HIP_OR_FREE(hipMalloc(&sc->blob, blob.bytes.size()));
     CRT_HIP_OR_FREE(hipMemcpy(sc->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice));
+    // (the copies above went through the null stream, which the scene's own stream does not wait for: everything has landed before the first render)
+    CRT_HIP_OR_FREE(hipStreamSynchronize(nullptr));
     CRT_HIP_OR_FREE(hipMalloc((void**)&sc->ray_counter, kCounterBytes + (size_t)2 * kMaxOrderedItems * sizeof(unsigned int)));
     sc->spill_entries = std::max(0, need - (stack_entries - 1));       // one LDS row is the row of -1 below the stacks
     sc->spill_threads = std::max(sc->cu_count * (4 * std::max(std::max(std::max(CRT_FLAT_BASIC_WAVES_PER_SIMD, CRT_FLAT_WAVES_PER_SIMD), std::max(CRT_TREE_WAVES_PER_SIMD, CRT_TREE_BASIC_WAVES_PER_SIMD)), CRT_WF_TRACE_WAVES_PER_SIMD) / kWaves), 1024) * kBlock;
@@ -2533,6 +2535,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
             sc->wf_cursors = reinterpret_cast<unsigned int*>(take(counters));
             sc->wf_block_rays = reinterpret_cast<unsigned long long*>(take(block_rays));
             e = hipMemset(sc->wf_block_rays, 0, block_rays);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);     // (runs on the null stream; the scene's stream does not wait for it)
             if (e != hipSuccess) return crt::set_error(CRT_ERR_DEVICE, std::string("crt_scene_create: ") + hipGetErrorString(e));
             for (int q = 0; q < 2; q++) {
                 sc->wf_queue[q].count = reinterpret_cast<unsigned int*>(take(seg_counts));
@@ -2593,7 +2596,11 @@ int crt_buffers_create(int width, int height, crt_buffers** out) {
     void* mem = nullptr;
     size_t bytes = (size_t)kPasses * width * height * sizeof(float);
     CRT_HIP(hipMalloc(&mem, bytes));
+    // (a memset of device memory returns before it has run, and it runs on the null stream, which the scenes' own
+    // non-blocking streams do not wait for: without the wait a render into the new buffers can be overtaken by
+    // their zeros - seen with eight processes on one GPU, whose queues take turns on the hardware)
     hipError_t e = hipMemset(mem, 0, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) { (void)hipFree(mem); return crt::set_error(CRT_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(e)); }
     crt_buffers* b = new crt_buffers();
     b->width = width; b->height = height; b->base = static_cast<float*>(mem); b->owned = true;
@@ -2642,6 +2649,7 @@ int crt_buffers_upload(crt_buffers* b, const float* color, const float* albedo, 
     if (normal) CRT_HIP(hipMemcpy(b->normal(), normal, n * 12, hipMemcpyHostToDevice));
     if (depth) CRT_HIP(hipMemcpy(b->depth(), depth, n * 4, hipMemcpyHostToDevice));
     if (opacity) CRT_HIP(hipMemcpy(b->opacity(), opacity, n * 4, hipMemcpyHostToDevice));
+    CRT_HIP(hipStreamSynchronize(nullptr));      // (a progressive render folds into these on a stream that does not wait for the null stream)
     return CRT_OK;
 }
 
