@@ -7,6 +7,9 @@ from cudaraytracer_amd import api
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box.yaml"
 root = os.path.join(os.path.dirname(__file__), "..", "scenes")
 sc = crt.load_scene(os.path.join(root, name), base_dir=root)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dev_options
+sc.set_options(**dev_options.from_env())
 sc.upload()
 buf = crt.create_buffer(sc)
 spp = sc.render_info.samples_per_pixel
