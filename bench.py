@@ -302,6 +302,14 @@ def main():
         # every rank sees the same two numbers and leaves together, before any collective
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; nothing was measured")
 
+    if launched:
+        # A rank keeps three renders in flight on three streams beside torch's stream and RCCL's: HIP spreads a
+        # process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by default), and two streams that share one
+        # run one after the other - a collective would wait behind a whole render.  Read when HIP starts, so set
+        # before anything touches the GPU.
+        if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
     # stdout carries exactly one line, the result; anything native libraries print on the way
     # (RCCL's version banner, for one) goes to stderr instead
     sys.stdout.flush()
@@ -383,22 +391,29 @@ def main():
             raise SystemExit(f"bench.py: {e}; nothing was measured")
         first, count = multi_gpu.split_samples(spp, world)[rank] if sharding == "samples" else (0, spp)
 
-    # Frames in flight: with more than one process the collective of frame k runs while frame k+1
-    # (and the start of k+2) renders, so three sets of buffers rotate; a frame's buffers are
-    # rendered into again only after its collective has finished.
-    # (three copies of the scene from eight processes on, see below: the buffers of a frame are in use from its
-    # launch to the end of its collective, one frame longer than its scene copy)
-    copies = 1 if not distributed else int(os.environ.get("CRT_BENCH_COPIES", "3" if world >= 8 else "2"))
-    depth = copies + 1 if distributed else 1
-    # With more than one process consecutive frames also render on two or three device copies of the scene (each
-    # has its own stream and scratch): a rank's share of the frame is short, and the last long paths of one frame
-    # then overlap the start of the next instead of leaving the GPU half empty (one rank's eighth of the Cornell
-    # frame: 1.38 ms per frame one at a time, 1.26 with two copies, 1.19 with three; a quarter: 2.29 / 2.11 / 2.09).
-    # A single-GPU run keeps one frame at a time, so that the kernel durations behind the roofline are those of a
-    # kernel that has the GPU to itself.
+    # Frames in flight: with more than one process the collective of frame k runs while frames k+1 ... render, so
+    # `copies` + 2 sets of buffers rotate (a frame's buffers are in use from its launch to the end of its collective)
+    # and are rendered into again only after their collective has finished.
+    # A rank's share of the frame is short, and a render ends on a few long paths in nearly empty waves: consecutive
+    # frames therefore render side by side on three device copies of the scene (own stream and scratch each), every
+    # one on a third of the chip (scene option chip_parts), so that one frame's tail runs beside the others' bulk.
+    # One rank's eighth of the Cornell frame, frames per time on one GPU (tools/pipeline_blocks.py): 1.10 ms one frame
+    # at a time, 0.98 with three full-size renders in flight, 0.87 with three on a third of the chip each; a quarter
+    # 1.91 / 1.75 / 1.68, a half 3.58 / 3.39 / 3.29.  A single-GPU run keeps one frame at a time on the whole chip, so
+    # that the kernel durations behind the roofline are those of a kernel that has the GPU to itself.
+    copies = 1 if not distributed else max(1, int(os.environ.get("CRT_BENCH_COPIES", "3")))
+    # (two more buffer sets than scene copies: the collective of frame j starts when frame j has rendered, `copies`
+    # iterations after its launch; with one spare set the host would wait for it in the very next iteration, before it
+    # launches the next frame, and a third of the chip would idle meanwhile)
+    depth = copies + 2 if distributed else 1
     scenes = [sc]
+    if copies > 1:
+        # (the first copy was uploaded for the whole chip - the sharding probe above renders on it alone - and is uploaded anew)
+        sc.set_options(chip_parts=copies)
+        sc.upload()
     for _ in range(copies - 1):
         other = crt.load_scene(scene_file, base_dir=os.path.join(ROOT, "scenes"))
+        other.set_options(chip_parts=copies)
         if args.spp > 0:
             other.set_render(samples=args.spp)
         other.upload()
@@ -446,13 +461,23 @@ def main():
         else:
             pending[slot] = multi_gpu.combine_means_async(passes[slot], count, total_spp, dist)
 
+    done_events = [torch.cuda.Event() for _ in range(depth)] if distributed else []
+
     def wait_for(slot):
+        """The collective that used this slot's buffers has finished (the host waits for it: the next render into
+        them runs on a scene's own stream); the copy kernel that lays the gathered bands out as the image is only
+        queued - with the chip full of render kernels it runs when one of them ends, and nothing waits for it here."""
         if pending[slot] is not None:
             pending[slot].wait()
+            if not shared_gpu:
+                done_events[slot].record()
             if sharding == "tiles":
                 crt.assemble_bands(image_buf, gathered[slot].data_ptr(), stride, band_rows, world,
                                    stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.current_stream().synchronize()
+            if shared_gpu:
+                torch.cuda.current_stream().synchronize()
+            else:
+                done_events[slot].synchronize()
             pending[slot] = None
 
     def run(steps):
@@ -472,16 +497,22 @@ def main():
             start_collective(k % depth)
 
         in_flight = []                                   # frames launched and not yet finished, oldest first
+        spent = [0.0, 0.0, 0.0]
         for k in range(steps):
             slot = k % depth
-            wait_for(slot)
+            t_a = time.perf_counter()
             if len(in_flight) == len(scenes):            # this frame's scene copy is still rendering frame k - len(scenes)
-                finish(in_flight.pop(0))
+                finish(in_flight.pop(0))                 # (its collective is queued before the next render kernel is)
+            t_b = time.perf_counter()
+            wait_for(slot)                               # the collective of frame k - depth, started two iterations ago
+            t_c = time.perf_counter()
             scene = scenes[k % len(scenes)]
             if sharding == "tiles":
                 crt.render_bands_launch(scene, bufs[slot], first, count, band_rows, rank, world)
             else:
                 crt.render_launch(scene, bufs[slot], first, count)
+            t_d = time.perf_counter()
+            spent[0] += t_b - t_a; spent[1] += t_c - t_b; spent[2] += t_d - t_c
             in_flight.append(k)
             if len(scenes) == 1:
                 finish(in_flight.pop(0))
@@ -489,6 +520,9 @@ def main():
             finish(in_flight.pop(0))
         for slot in range(depth):
             wait_for(slot)
+        if os.environ.get("CRT_BENCH_PHASES") and steps:
+            print(f"rank {rank}: {steps} frames, host ms per frame in finish+start_collective {spent[0] / steps * 1e3:.3f}, "
+                  f"wait_for {spent[1] / steps * 1e3:.3f}, launch {spent[2] / steps * 1e3:.3f}", file=sys.stderr)
         return rays, trace_ms, resolve_ms
 
     def fence():

@@ -71,7 +71,7 @@ class crt_scene_desc(C.Structure):
 class crt_scene_options(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("accel", C.c_int32), ("mode", C.c_int32), ("ieee_division", C.c_int32),
                 ("work_items", C.c_int32), ("blocks", C.c_int32), ("ready_percent", C.c_int32), ("prim_batch", C.c_int32),
-                ("deterministic", C.c_int32), ("wavefront", C.c_int32), ("wavefront_paths", C.c_int32), ("flat_cuboids", C.c_int32), ("general_kernel", C.c_int32), ("exact_ties", C.c_int32), ("item_order", C.c_int32)]
+                ("deterministic", C.c_int32), ("wavefront", C.c_int32), ("wavefront_paths", C.c_int32), ("flat_cuboids", C.c_int32), ("general_kernel", C.c_int32), ("exact_ties", C.c_int32), ("item_order", C.c_int32), ("chip_parts", C.c_int32)]
 
 
 ACCEL_AUTO, ACCEL_REFERENCE, ACCEL_ORDERED = 0, 1, 2

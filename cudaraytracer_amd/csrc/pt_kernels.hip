@@ -1729,6 +1729,13 @@ ChunkPlan plan_chunks(const crt_scene* sc, int mode, int samples, size_t capacit
     // paths of very different lengths - glass spheres, 30 bounces - still gain 3 % at 131072, scenes with short paths lose 3 %)
     const int target_items = sc->opt.work_items > 0 ? sc->opt.work_items : 98304;
     long long chunks = sc->opt.deterministic ? samples : std::min<long long>(samples, std::max<long long>(1, ((long long)target_items + p.ntiles - 1) / p.ntiles));
+    // A chunk holds at least eight samples where the launch has them (256 paths per item): a small cut of a frame - a
+    // reduced image, one rank's bands of the tile split - would otherwise fall into items of one or two wave-fulls, and
+    // taking and flushing an item (14 x 32 sums) then costs as much as tracing it.  Measured, one frame at a time: an eighth
+    // of the Cornell frame 1.33 -> 1.10 ms, Cornell at 256 x 256 0.80 -> 0.69, materials at 500 x 100 1.29 -> 0.92, the
+    // orthographic cube at 256 x 256 and 8 samples 0.18 -> 0.09 (tools/items_sweep.py); whole frames of the usual sizes
+    // are cut as before.
+    if (!sc->opt.deterministic && sc->opt.work_items == 0) chunks = std::min<long long>(chunks, std::max<long long>(1, samples / 8));
     p.fits = chunk_bytes <= capacity;
     if (!sc->opt.deterministic) chunks = std::max<long long>(1, std::min<long long>(chunks, (long long)(capacity / chunk_bytes)));
     else if ((size_t)chunks * chunk_bytes > capacity) p.fits = false;
@@ -1859,6 +1866,7 @@ static int scene_create(const crt_scene_desc* d, const crt_scene_options* option
     if (opt.flat_cuboids < 0 || opt.flat_cuboids > 3) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->flat_cuboids must be 0..3");
     if (opt.wavefront < 0 || opt.wavefront > 2 || opt.wavefront_paths < 0) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->wavefront must be 0..2 and wavefront_paths >= 0");
     if (opt.item_order < 0 || opt.item_order > 2) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->item_order must be 0, 1 or 2");
+    if (opt.chip_parts < 0 || opt.chip_parts > 16) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->chip_parts must be 0..16");
     if (opt.exact_ties < 0 || opt.exact_ties > 1) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->exact_ties must be 0 or 1");
     if (opt.work_items > (1 << 26)) return crt::set_error(CRT_ERR_INVALID, "crt_scene_create: options->work_items must not exceed 67 108 864");
     if (opt.work_items < 0 || opt.blocks < 0 || opt.ready_percent < 0 || opt.ready_percent > 100 || opt.prim_batch < 0 || opt.prim_batch > 64)
@@ -2727,6 +2735,7 @@ static int launch_render(crt_scene* sc, crt_buffers* buf, int first_sample, int 
     const long long items = (long long)plan.ntiles * plan.chunks;
     int resident = sc->cu_count * (4 * waves_per_simd(kernel_mode(sc), variant_features(sc)) / kWaves);   // 4 SIMDs per CU
     if (sc->opt.blocks > 0) resident = std::min(sc->spill_threads / kBlock, sc->opt.blocks);
+    else if (sc->opt.chip_parts > 1) resident = std::max(1, resident / sc->opt.chip_parts);
     dim3 grid((unsigned)std::min<long long>((items + kWaves - 1) / kWaves, resident));
     CRT_HIP(hipEventRecord(sc->ev_start, sc->stream));
     const bool wavefront = sc->wavefront && kernel_mode(sc) == kModeTreeGlobal;

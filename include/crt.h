@@ -206,6 +206,11 @@ typedef struct crt_scene_options {
                                  from the reference in about one path in 10^8 (a ray through an edge that lies in a
                                  box face)                                                             */
     int32_t item_order;       /* described in crt_dev.h (0 = default)                                   */
+    int32_t chip_parts;       /* n > 1: a render of this scene occupies 1/n of the GPU (its persistent kernel is
+                                 started with 1/n of the workgroups that fill the chip).  For a caller that keeps n
+                                 renders in flight on n scene copies (crt_render_launch on each, then
+                                 crt_render_finish): side by side, each render's last long paths overlap the
+                                 others' bulk instead of leaving the GPU half empty.  0 or 1 (default): the whole GPU */
 } crt_scene_options;
 int crt_scene_options_init(crt_scene_options* options);
 

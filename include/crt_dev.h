@@ -15,7 +15,8 @@ extern "C" {
 #endif
 
 /* Fields of crt_scene_options (crt.h) for tuning and comparison; 0 = the library's choice.
- *   work_items      work items (pixel tile x sample chunk) a frame is cut into; 0 = 98304
+ *   work_items      work items (pixel tile x sample chunk) a frame is cut into; 0 = 98304, but no chunk under eight
+ *                   samples where the launch has that many (a value given here is taken as it is)
  *   blocks          workgroups of the persistent render kernel; 0 = fill the GPU
  *   ready_percent   tree walk: shade once this share of a wave's rays is done; 0 = 65 (45 for hierarchies beyond 4 MB)
  *   prim_batch      tree walk: lanes with leaf candidates that start a test round; 0 = 8 (2 or 16 for hierarchies beyond 4 MB)

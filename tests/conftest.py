@@ -20,6 +20,13 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def crt():
+    # PyTorch's wheel carries a HIP runtime of its own beside the system's one that libcrt_hip.so is linked against.
+    # Both work in one process when torch's is loaded first; loaded second it finds no GPU ("No HIP GPUs are
+    # available").  Tests that hand torch tensors to the library import torch inside the test, so do it here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import cudaraytracer_amd
     return cudaraytracer_amd
 

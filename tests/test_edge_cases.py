@@ -76,7 +76,7 @@ def test_invalid_descriptions_are_refused(crt):
     assert create(crt, d)[0] == -1
 
     # options out of range (a work item count near INT_MAX would overflow the chunk arithmetic)
-    for field, value in (("work_items", 2**31 - 1), ("work_items", (1 << 26) + 1), ("exact_ties", 2), ("item_order", 3), ("flat_cuboids", 4), ("prim_batch", 65)):
+    for field, value in (("work_items", 2**31 - 1), ("work_items", (1 << 26) + 1), ("exact_ties", 2), ("item_order", 3), ("chip_parts", 17), ("chip_parts", -1), ("flat_cuboids", 4), ("prim_batch", 65)):
         other = crt.parse_scene(MINI)
         other.set_options(**{field: value})
         with pytest.raises(crt.CrtError) as e:

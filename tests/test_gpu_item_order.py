@@ -61,3 +61,32 @@ def test_item_order_option_range(crt):
     with pytest.raises(CrtError, match="item_order"):
         sc.upload()
     sc.close()
+
+
+def test_renders_side_by_side_on_parts_of_the_chip(crt):
+    """chip_parts = 3: a render's persistent kernel takes a third of the GPU, for callers that keep three renders in
+    flight on three copies of the scene (the N-rank bench).  The image of each is the one a render alone on the whole
+    chip gives, bit for bit (one sample per launch), and so is the ray count."""
+    from cudaraytracer_amd import api
+    name, w, h = "cornell_box.yaml", 160, 160
+    ref, ref_rays = _render(crt, name, w, h, {"item_order": 1})
+    scenes, bufs = [], []
+    for _ in range(3):
+        sc = crt.load_scene(scene_path(name), base_dir=SCENE_DIR)
+        sc.set_render(w, h, samples=LAUNCHES)
+        sc.set_options(chip_parts=3, item_order=1)
+        sc.upload()
+        scenes.append(sc)
+        bufs.append(crt.create_buffer(sc))
+    for sc, buf in zip(scenes, bufs):                       # sample number 1 of every pixel, three times over, together
+        api.render_launch(sc, buf, 0, 1)
+    for sc, buf in zip(scenes, bufs):
+        _, rays = api.render_finish(sc)
+        assert rays == ref_rays[0]
+        got = buf.download()
+        for k in got:
+            same = (got[k].view(np.uint32) == ref[0][k].view(np.uint32)) | (np.isnan(got[k]) & np.isnan(ref[0][k]))
+            assert same.all(), f"pass {k} differs at {np.flatnonzero(~same)[:8]}"
+    for sc, buf in zip(scenes, bufs):
+        buf.close()
+        sc.close()

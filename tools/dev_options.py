@@ -16,7 +16,7 @@ def from_env(env=os.environ):
         opt["ieee_division"] = 1
     for var, name in (("CRT_TARGET_WAVES", "work_items"), ("CRT_BLOCKS", "blocks"), ("CRT_READY_PERCENT", "ready_percent"),
                       ("CRT_PRIM_BATCH", "prim_batch"), ("CRT_DETERMINISTIC", "deterministic"), ("CRT_WAVEFRONT", "wavefront"),
-                      ("CRT_WAVEFRONT_PATHS", "wavefront_paths"), ("CRT_FLAT_CUBOIDS", "flat_cuboids"), ("CRT_GENERAL_KERNEL", "general_kernel"), ("CRT_EXACT_TIES", "exact_ties"), ("CRT_ITEM_ORDER", "item_order")):
+                      ("CRT_WAVEFRONT_PATHS", "wavefront_paths"), ("CRT_FLAT_CUBOIDS", "flat_cuboids"), ("CRT_GENERAL_KERNEL", "general_kernel"), ("CRT_EXACT_TIES", "exact_ties"), ("CRT_ITEM_ORDER", "item_order"), ("CRT_CHIP_PARTS", "chip_parts")):
         if var in env:
             opt[name] = int(env[var])
     return opt
