@@ -401,7 +401,9 @@ def main():
     # at a time, 0.98 with three full-size renders in flight, 0.87 with three on a third of the chip each; a quarter
     # 1.91 / 1.75 / 1.68, a half 3.58 / 3.39 / 3.29.  A single-GPU run keeps one frame at a time on the whole chip, so
     # that the kernel durations behind the roofline are those of a kernel that has the GPU to itself.
-    copies = 1 if not distributed else max(1, int(os.environ.get("CRT_BENCH_COPIES", "3")))
+    # (a scene whose tables go far beyond the 4 MB of an XCD's L2 - a million triangles - keeps one frame at a time: every
+    # copy is walked through the caches on its own, and three working sets side by side only evict each other)
+    copies = 1 if not distributed else max(1, int(os.environ.get("CRT_BENCH_COPIES", "3" if sc.desc.object_count <= 65536 else "1")))
     # (two more buffer sets than scene copies: the collective of frame j starts when frame j has rendered, `copies`
     # iterations after its launch; with one spare set the host would wait for it in the very next iteration, before it
     # launches the next frame, and a third of the chip would idle meanwhile)
