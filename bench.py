@@ -274,7 +274,9 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = the scene's frame divided over the GPUs (default), weak = the scene's spp per GPU")
     ap.add_argument("--sharding", choices=("auto", "samples", "tiles"), default="auto", help="how a strong-scaling frame is divided")
-    ap.add_argument("--cpu-spp", type=int, default=50, help="samples per pixel of the CPU baseline's all-threads leg (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=None,
+                    help="samples per pixel of the CPU baseline's all-threads leg (0 = skip; default 50 on the headline scene, 0 on any other: "
+                         "the CPU restatement needs hours for a frame of the large scenes)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-configs", action="store_true", help="N = 1, headline scene: skip the other BASELINE configurations")
     ap.add_argument("--check", action="store_true",
@@ -285,6 +287,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.cpu_spp is None:
+        args.cpu_spp = 50 if args.scene == HEADLINE else 0
 
     if os.environ.get("CRT_BENCH_TRACE_AFTER"):
         # debugging aid: every process prints where it stands after that many seconds and exits
