@@ -14,6 +14,8 @@ FULL = 1536            # blocks that fill the chip at six waves per SIMD (256 CU
 settle, frames = 24, 200
 for world in worlds:
     sweep = [(1, 0, 0), (2, 0, 0), (3, 0, 0), (2, FULL // 2, 0), (3, FULL // 3, 0), (3, FULL // 2, 0)]
+    if os.environ.get("SWEEP") == "copies":
+        sweep = [(2, FULL // 2, 0), (3, FULL // 3, 0), (4, FULL // 4, 0), (5, FULL // 5, 0), (6, FULL // 6, 0)]
     if os.environ.get("SWEEP") == "items":
         sweep = [(3, FULL // 3, n) for n in (0, 65536, 49152, 32768, 24576, 16384)] + [(3, 0, n) for n in (49152, 24576)] + [(2, FULL // 2, n) for n in (49152, 24576)]
     for copies, blocks, items in sweep:
