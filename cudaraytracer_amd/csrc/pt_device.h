@@ -137,7 +137,10 @@ enum : int {
     kFeatBasicXform = kFeatXform,  // the same with transformed objects (rotated boxes)
     // any shapes, transforms and camera kinds under diffuse materials and lights of one colour, environment of one colour
     // (no textures or normal maps, no metal or glass: none of the code that looks things up per hit)
-    kFeatPlain = kFeatPlainXf | kFeatSphere | kFeatSlotXf | kFeatCamera | kFeatXform
+    kFeatPlain = kFeatPlainXf | kFeatSphere | kFeatSlotXf | kFeatCamera | kFeatXform,
+    // every shape, material and texture kind seen through the pinhole camera without defocus or moving spheres, under an
+    // environment of one colour, in at most 32 slots
+    kFeatTextured = kFeatAll & ~(kFeatWide | kFeatCamera | kFeatEnvTexture)
 };
 
 struct DevImage {

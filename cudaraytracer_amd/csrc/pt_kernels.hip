@@ -1492,6 +1492,7 @@ int variant_features(const crt_scene* sc) {
     if (kernel_mode(sc) == kModeFlat) {
         if ((sc->features & ~kFeatBasicXform) == 0) return kFeatBasicXform;
         if ((sc->features & ~kFeatPlain) == 0) return kFeatPlain;
+        if ((sc->features & ~kFeatTextured) == 0) return kFeatTextured;
         return (sc->features & kFeatWide) ? kFeatAll : (kFeatAll & ~kFeatWide);
     }
     // the flat mode's feature bits say nothing about a tree walk
@@ -1503,6 +1504,7 @@ void launch_flat(crt_scene* sc, const RenderArgs& A, dim3 grid, size_t lds) {
     switch (variant_features(sc)) {
     case kFeatBasicXform: launch_flat_feat<GROUPS, kFeatBasicXform>(sc, A, grid, lds); break;
     case kFeatPlain: launch_flat_feat<GROUPS, kFeatPlain>(sc, A, grid, lds); break;
+    case kFeatTextured: launch_flat_feat<GROUPS, kFeatTextured>(sc, A, grid, lds); break;
     case kFeatAll & ~kFeatWide: launch_flat_feat<GROUPS, kFeatAll & ~kFeatWide>(sc, A, grid, lds); break;
     default: launch_flat_feat<GROUPS, kFeatAll>(sc, A, grid, lds); break;
     }
