@@ -601,6 +601,10 @@ def main():
         value = rays_total / elapsed / 1e6
         roofline = roofline_block(args.scene, rays_rank / args.steps, trace_ms / args.steps, resolve_ms / args.steps,
                                   world == 1 and args.spp == 0)
+        if roofline is not None and len(scenes) > 1:
+            roofline["frames_in_flight"] = len(scenes)
+            roofline["note"] = (f"{len(scenes)} renders run side by side, each on 1/{len(scenes)} of the chip: kernel_ms is the duration of a kernel "
+                                f"that has a part of the GPU, and achieved / frac follow from it; the single-GPU line has the kernel alone on the chip")
         if not distributed:
             how = "single GPU"
         elif sharding == "tiles":
