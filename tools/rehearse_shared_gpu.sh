@@ -9,7 +9,7 @@ RANKS=${*:-2 3 8}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 PORT=29520
 for N in $RANKS; do
-  for MODE in "--sharding tiles" "--sharding samples" "--sharding auto"; do
+  for MODE in "--sharding tiles" "--sharding samples" "--sharding auto" "--scaling weak"; do
     M=$(echo $MODE | tr -d ' -')
     PORT=$((PORT + 1))
     CRT_BENCH_TRACE_AFTER=90 CRT_BENCH_SHARED_GPU=1 timeout -k 10 240 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT \
